@@ -1,0 +1,287 @@
+"""Golden-vector generator — runs ONLY in the build container (needs /root/reference).
+
+Imports the reference implementation on CPU (two harness-side shims, no edit of the reference:
+a `timm` stub for `trunc_normal_`, and `Tensor.cuda` -> identity because `get_grid` hard-codes
+`.cuda()`), then
+
+  1. asserts that `oracle/transolver_oracle.py` reproduces the reference (forward, loss and every
+     parameter gradient) on the same weights and inputs, and
+  2. writes the fixtures `tests/golden/G*.npz` (inputs + expected outputs produced BY THE
+     REFERENCE) that the CPU tests use to pin the oracle and the GPU tests use to pin the HIP path.
+
+Weights/inputs come from the build-owned seeded generators in
+`transformerbasednavierstokesolver_amd.synth`, so large tensors are regenerated from the seed on
+the GPU box instead of being committed.  Usage:  python oracle/make_golden.py
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+from transformerbasednavierstokesolver_amd import synth  # noqa: E402
+from oracle import transolver_oracle as orc  # noqa: E402
+
+
+def import_reference():
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REF)
+    tl = types.ModuleType("timm.models.layers")
+    tl.trunc_normal_ = torch.nn.init.trunc_normal_
+    sys.modules.update({"timm": types.ModuleType("timm"), "timm.models": types.ModuleType("timm.models"),
+                        "timm.models.layers": tl})
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    from model.Transolver_Structured_Mesh_2D import Model
+    from model.Physics_Attention import Physics_Attention_Structured_Mesh_2D as Attn
+    from model.SOL_Transolver_Structured_Mesh_2D import SOL_Transolver_Structured_Mesh_2D as SOL
+    from utils.testloss import TestLoss
+    return Model, Attn, SOL, TestLoss
+
+
+def ref_model(Model, cfg, sd_np, dtype):
+    m = Model(space_dim=cfg["space_dim"], n_layers=cfg["n_layers"], n_hidden=cfg["n_hidden"],
+              dropout=0.0, n_head=cfg["n_head"], Time_Input=cfg["Time_Input"], act=cfg["act"],
+              mlp_ratio=cfg["mlp_ratio"], fun_dim=cfg["fun_dim"], out_dim=cfg["out_dim"],
+              slice_num=cfg["slice_num"], ref=cfg["ref"], unified_pos=cfg["unified_pos"],
+              H=cfg["H"], W=cfg["W"])
+    missing = m.load_state_dict({k: torch.from_numpy(v) for k, v in sd_np.items()}, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    m = m.to(dtype)
+    if cfg["unified_pos"]:
+        m.pos = m.pos.to(dtype)
+    return m
+
+
+def rel(a, b):
+    a = torch.as_tensor(a, dtype=torch.float64)
+    b = torch.as_tensor(b, dtype=torch.float64)
+    return float((a - b).norm() / b.norm().clamp_min(1e-300))
+
+
+def sample(t, n=257):
+    f = np.asarray(t, dtype=np.float64).ravel()
+    stride = max(1, f.size // n)
+    return f[::stride][:n].copy(), stride
+
+
+def check(name, got, want, tol):
+    e = rel(got, want)
+    print(f"  [{'ok' if e <= tol else 'FAIL'}] {name}: rel-L2 {e:.3e} (tol {tol:.0e})")
+    assert e <= tol, name
+
+
+def g1_tiny(Model, TestLoss):
+    """Tiny full-model case: fp64 + fp32 reference outputs, loss and all gradients.  Includes
+    temperatures outside [0.1, 5] so the clamp mask is pinned."""
+    cfg = synth.TINY_CONFIG
+    sd = synth.synth_state_dict(cfg, seed=11, wild_temperature=True)
+    B, N = 2, cfg["H"] * cfg["W"]
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((B, N, 2)).astype(np.float32)
+    fx = rng.standard_normal((B, N, cfg["fun_dim"])).astype(np.float32)
+    y = rng.standard_normal((B, N, cfg["out_dim"])).astype(np.float32)
+    out = dict(x=x, fx=fx, y=y)
+    out.update({"sd." + k: v for k, v in sd.items()})
+    myloss = TestLoss(size_average=False)
+    for dtype, tag, tol in ((torch.float64, "f64", 1e-12), (torch.float32, "f32", 2e-5)):
+        m = ref_model(Model, cfg, sd, dtype)
+        xt, fxt, yt = (torch.from_numpy(a).to(dtype) for a in (x, fx, y))
+        pred = m(xt, fx=fxt)
+        loss = myloss(pred.reshape(B, -1), yt.reshape(B, -1))
+        loss.backward()
+        out[f"pred.{tag}"] = pred.detach().numpy()
+        out[f"loss.{tag}"] = np.asarray(loss.item())
+        sdo = orc.to_torch(sd, dtype, requires_grad=True)
+        po = orc.model_forward(sdo, xt, fxt, cfg)
+        lo = orc.rel_l2(po.reshape(B, -1), yt.reshape(B, -1))
+        lo.backward()
+        check(f"G1 {tag} forward", po.detach(), pred.detach(), tol)
+        for k, p in m.named_parameters():
+            if p.grad is None:
+                assert k == "placeholder" and sdo[k].grad is None
+                continue
+            out[f"grad.{tag}.{k}"] = p.grad.numpy()
+            check(f"G1 {tag} grad {k}", sdo[k].grad, p.grad, tol * 50)
+    np.savez(os.path.join(GOLD, "G1_tiny.npz"), **out)
+
+
+def g1b_tiny_branches(Model):
+    """fx=None (placeholder) + Time_Input branches of Model.forward (…_2D.py:208-215), forward only."""
+    cfg = dict(synth.TINY_CONFIG, fun_dim=0, Time_Input=True, unified_pos=0)
+    sd = synth.synth_state_dict(cfg, seed=12)
+    B, N = 2, cfg["H"] * cfg["W"]
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal((B, N, 2)).astype(np.float32)
+    T = np.array([0.25, 3.0], dtype=np.float32)
+    # the reference computes the time embedding in float32 whatever the model dtype, so fp32 only
+    m = ref_model(Model, cfg, sd, torch.float32)
+    with torch.no_grad():
+        pred = m(torch.from_numpy(x), None, T=torch.from_numpy(T).reshape(B, 1))
+    sdo = orc.to_torch(sd, torch.float32)
+    po = orc.model_forward(sdo, torch.from_numpy(x), None, cfg, T=torch.from_numpy(T).reshape(B, 1))
+    check("G1b fx=None + T forward", po, pred.detach(), 2e-5)
+    np.savez(os.path.join(GOLD, "G1b_tiny_branches.npz"), x=x, T=T, pred=pred.detach().numpy())
+
+
+def g2_attn(Attn):
+    """Physics-Attention module alone at the NS shape (B=1, 64x64, C=256, h=8, M=64)."""
+    cfg = synth.NS_CONFIG
+    sd_all = synth.synth_state_dict(dict(cfg, n_layers=1), seed=21)
+    pre = "blocks.0.Attn."
+    sd = {k[len(pre):]: v for k, v in sd_all.items() if k.startswith(pre)}
+    C, h = cfg["n_hidden"], cfg["n_head"]
+    a = Attn(C, heads=h, dim_head=C // h, dropout=0.0, slice_num=cfg["slice_num"], H=64, W=64).double()
+    a.load_state_dict({k: torch.from_numpy(v).double() for k, v in sd.items()}, strict=True)
+    rng = np.random.default_rng(22)
+    x = rng.standard_normal((1, 4096, C)).astype(np.float32)
+    gy = rng.standard_normal((1, 4096, C)).astype(np.float32)
+    xt = torch.from_numpy(x).double().requires_grad_(True)
+    y = a(xt)
+    y.backward(torch.from_numpy(gy).double())
+    sdo = orc.to_torch({pre + k: v for k, v in sd.items()}, torch.float64, requires_grad=True)
+    xo = torch.from_numpy(x).double().requires_grad_(True)
+    yo = orc.physics_attention(xo, sdo, pre, 64, 64, h)
+    yo.backward(torch.from_numpy(gy).double())
+    check("G2 attn forward", yo.detach(), y.detach(), 1e-12)
+    check("G2 attn dx", xo.grad, xt.grad, 1e-11)
+    out = {}
+    out["y.sample"], out["y.stride"] = sample(y.detach())
+    out["y.norm"] = np.asarray(float(y.detach().norm()))
+    out["dx.sample"], out["dx.stride"] = sample(xt.grad)
+    out["dx.norm"] = np.asarray(float(xt.grad.norm()))
+    for k, p in a.named_parameters():
+        check(f"G2 attn grad {k}", sdo[pre + k].grad, p.grad, 1e-10)
+        out[f"grad.norm.{k}"] = np.asarray(float(p.grad.norm()))
+        out[f"grad.sample.{k}"], _ = sample(p.grad, 129)
+    np.savez(os.path.join(GOLD, "G2_attn_ns.npz"), **out)
+
+
+def g3_shipped_rollout(Model):
+    """The reference's own trained weights (checkpoints/ep400_sim100.pt, safe loader), 20-step
+    prediction-feedback rollout on seeded synthetic fields.  The weights are committed as an npz
+    data fixture (2.9 MB) so the GPU box can replay the rollout."""
+    sd_t = torch.load(os.path.join(REF, "checkpoints", "ep400_sim100.pt"), map_location="cpu",
+                      weights_only=True)
+    sd = {k: v.numpy().astype(np.float32) for k, v in sd_t.items()}
+    np.savez_compressed(os.path.join(GOLD, "ckpt_ep400_sim100.npz"), **sd)
+    cfg = synth.NS_SMALL_CONFIG
+    spec = {k: s for k, s, _ in synth.state_dict_spec(cfg)}
+    assert set(spec) == set(sd) and all(tuple(sd[k].shape) == tuple(spec[k]) for k in sd)
+    pos, a, u = synth.ns_batch(2, seed=31)
+    out = dict(sha256=np.frombuffer(hashlib.sha256(
+        open(os.path.join(REF, "checkpoints", "ep400_sim100.pt"), "rb").read()).digest(), dtype=np.uint8))
+    for dtype, tag, tol in ((torch.float64, "f64", 1e-11), (torch.float32, "f32", 2e-4)):
+        m = ref_model(Model, cfg, sd, dtype).eval()
+        x, fx = torch.from_numpy(pos).to(dtype), torch.from_numpy(a).to(dtype)
+        frames = []
+        with torch.no_grad():
+            for t in range(20):
+                im = m(x, fx=fx)
+                frames.append(im)
+                fx = torch.cat((fx[..., 1:], im), dim=-1)
+        fr = torch.cat(frames, -1)
+        fo = orc.rollout(orc.to_torch(sd, dtype), torch.from_numpy(pos).to(dtype),
+                         torch.from_numpy(a).to(dtype), cfg, 20)
+        check(f"G3 rollout {tag}", fo, fr, tol)
+        for t in (0, 4, 9, 19):
+            out[f"frame{t + 1}.{tag}.sample"], out["stride"] = sample(fr[..., t])
+            out[f"frame{t + 1}.{tag}.norm"] = np.asarray(float(fr[..., t].double().norm()))
+    np.savez(os.path.join(GOLD, "G3_shipped_rollout.npz"), **out)
+
+
+def g4_train_iteration(Model, TestLoss):
+    """One exp_ns-style mini-batch (B=2, C=64, M=32, T=10 teacher-forced calls, summed rel-L2,
+    backward) + one AdamW(wd=1e-5)/OneCycleLR step, reference in fp64."""
+    cfg = synth.NS_SMALL_CONFIG
+    sd = synth.synth_state_dict(cfg, seed=41)
+    pos, a, u = synth.ns_batch(2, seed=42)
+    B, T = 2, 10
+    m = ref_model(Model, cfg, sd, torch.float64).train()
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-5)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-3, epochs=5, steps_per_epoch=7)
+    myloss = TestLoss(size_average=False)
+    x, fx, yy = (torch.from_numpy(t).double() for t in (pos, a, u))
+    loss = 0
+    preds = []
+    for t in range(T):
+        y = yy[..., t:t + 1]
+        im = m(x, fx=fx)
+        loss = loss + myloss(im.reshape(B, -1), y.reshape(B, -1))
+        preds.append(im)
+        fx = torch.cat((fx[..., 1:], y), dim=-1)
+    pred = torch.cat(preds, -1)
+    full = myloss(pred.reshape(B, -1), yy.reshape(B, -1))
+    opt.zero_grad()
+    loss.backward()
+    out = dict(loss=np.asarray(loss.item()), full=np.asarray(full.item()))
+    out["pred.sample"], out["pred.stride"] = sample(pred.detach())
+    sdo = orc.to_torch(sd, torch.float64, requires_grad=True)
+    lo, fo, po, go = orc.train_iteration(sdo, torch.from_numpy(pos).double(), torch.from_numpy(a).double(),
+                                         torch.from_numpy(u).double(), cfg)
+    check("G4 loss", lo, loss.detach(), 1e-12)
+    check("G4 full loss", fo, full.detach(), 1e-12)
+    for k, p in m.named_parameters():
+        if p.grad is None:
+            assert k == "placeholder"
+            continue
+        check(f"G4 grad {k}", go[k], p.grad, 1e-9)
+        out[f"grad.norm.{k}"] = np.asarray(float(p.grad.norm()))
+        out[f"grad.sample.{k}"], _ = sample(p.grad, 65)
+    opt.step()
+    sched.step()
+    for k, p in m.named_parameters():
+        out[f"param1.norm.{k}"] = np.asarray(float(p.detach().norm()))
+        out[f"param1.sample.{k}"], _ = sample(p.detach(), 65)
+    out["lr1"] = np.asarray(sched.get_last_lr()[0])
+    np.savez(os.path.join(GOLD, "G4_train_iteration.npz"), **out)
+
+
+def g5_full_ns(Model, TestLoss):
+    """BASELINE configs[1] model (C=256, M=64, 8 layers) forward + one-call backward, B=1, fp64."""
+    cfg = synth.NS_CONFIG
+    sd = synth.synth_state_dict(cfg, seed=51)
+    pos, a, u = synth.ns_batch(1, seed=52)
+    m = ref_model(Model, cfg, sd, torch.float64)
+    x, fx, y = (torch.from_numpy(t).double() for t in (pos, a, u[..., :1]))
+    pred = m(x, fx=fx)
+    loss = TestLoss(size_average=False)(pred.reshape(1, -1), y.reshape(1, -1))
+    loss.backward()
+    sdo = orc.to_torch(sd, torch.float64, requires_grad=True)
+    po = orc.model_forward(sdo, x, fx, cfg)
+    lo = orc.rel_l2(po.reshape(1, -1), y.reshape(1, -1))
+    lo.backward()
+    check("G5 forward", po.detach(), pred.detach(), 1e-12)
+    out = dict(loss=np.asarray(loss.item()), pred=pred.detach().numpy().astype(np.float64).reshape(-1))
+    for k, p in m.named_parameters():
+        if p.grad is None:
+            continue
+        check(f"G5 grad {k}", sdo[k].grad, p.grad, 1e-9)
+        out[f"grad.norm.{k}"] = np.asarray(float(p.grad.norm()))
+        out[f"grad.sample.{k}"], _ = sample(p.grad, 65)
+    np.savez_compressed(os.path.join(GOLD, "G5_full_ns.npz"), **out)
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    torch.manual_seed(0)
+    Model, Attn, SOL, TestLoss = import_reference()
+    for name, fn in (("G1", lambda: g1_tiny(Model, TestLoss)), ("G1b", lambda: g1b_tiny_branches(Model)),
+                     ("G2", lambda: g2_attn(Attn)), ("G3", lambda: g3_shipped_rollout(Model)),
+                     ("G4", lambda: g4_train_iteration(Model, TestLoss)),
+                     ("G5", lambda: g5_full_ns(Model, TestLoss))):
+        print(name)
+        fn()
+    print("golden fixtures written to", GOLD)
+
+
+if __name__ == "__main__":
+    main()
