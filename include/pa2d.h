@@ -1,0 +1,127 @@
+/* libpa2d — C ABI of the MI355X-native Transolver Physics-Attention hot path.
+ *
+ * Drop-in boundary.  The reference has NO native layer: every stage below is what
+ * stock PyTorch dispatches from the Python lines cited per function (paths relative to the
+ * reference repo OnurBasci/TransformerBasedNavierStokeSolver).  A maintainer binds these symbols
+ * with ctypes from a replacement of model/Physics_Attention.py /
+ * model/Transolver_Structured_Mesh_2D.py; the shipped binding is
+ * transformerbasednavierstokesolver_amd/_lib.py.
+ *
+ * Conventions
+ *   - all tensors fp32, row-major, device pointers; "ld*" = row pitch in floats;
+ *   - the caller owns every buffer (outputs and workspaces); nothing here allocates, frees or
+ *     synchronises, there is no static state -> safe under hipGraph capture and on any stream;
+ *   - hipStream_t is passed as void* (torch.cuda.current_stream().cuda_stream);
+ *   - return value: 0 = ok, otherwise a hipError_t or PA2D_ERR_* (never a silent fallback);
+ *   - activation ids follow the reference's ACTIVATION table (…_2D.py:9-10).
+ */
+#ifndef PA2D_H
+#define PA2D_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* pa2d_stream_t;
+
+#define PA2D_OK 0
+#define PA2D_ERR_ARG 1001          /* alignment / shape contract violated */
+#define PA2D_ERR_UNSUPPORTED 1002  /* size outside the compiled kernel grid */
+#define PA2D_ERR_WORKSPACE 1003    /* caller workspace too small */
+
+enum pa2d_act { PA2D_ACT_NONE = 0, PA2D_ACT_GELU = 1, PA2D_ACT_TANH = 2, PA2D_ACT_SIGMOID = 3,
+                PA2D_ACT_RELU = 4, PA2D_ACT_SOFTPLUS = 5, PA2D_ACT_ELU = 6, PA2D_ACT_SILU = 7 };
+
+const char* pa2d_version(void);
+
+/* ---- LayerNorm: nn.LayerNorm(C) of Transolver_block, model/Transolver_Structured_Mesh_2D.py:58,62,65,70-73 */
+int pa2d_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
+                       float* rstd, int rows, int C, float eps, pa2d_stream_t stream);
+size_t pa2d_layernorm_bwd_workspace(int rows, int C);
+/* dx = LN'(dy) (+ dres: gradient of the residual branch `+ fx`, …_2D.py:70-71); dgamma/dbeta reduced */
+int pa2d_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd,
+                       const float* gamma, const float* dres, float* dx, float* dgamma, float* dbeta,
+                       void* ws, size_t ws_bytes, int rows, int C, pa2d_stream_t stream);
+
+/* ---- dense layers: nn.Linear of MLP (…_2D.py:26-38), to_out (Physics_Attention.py:81-84,119)
+ * y[M,N] = act(x[M,K] . w[N,K]^T + bias) (+ res);  pre (optional) receives the pre-activation.
+ * Requires K % 4 == 0 and ldx, ldw % 4 == 0. */
+int pa2d_gemm_bias_act_fwd(const float* x, long long ldx, const float* w, long long ldw, const float* bias,
+                           const float* res, long long ldres, float* y, long long ldy, float* pre,
+                           long long ldpre, int M, int N, int K, int act, pa2d_stream_t stream);
+/* dx[M,K] = (dy[M,N] . w[N,K]) * act'(pre[M,K])  (pre NULL -> no activation factor);
+ * wt_ws: K*N floats scratch (transposed weight). */
+int pa2d_gemm_bwd_data(const float* dy, long long lddy, const float* w, long long ldw, const float* pre,
+                       long long ldpre, int act, float* dx, long long lddx, float* wt_ws, int M, int N, int K,
+                       pa2d_stream_t stream);
+size_t pa2d_gemm_bwd_weight_workspace(int M, int N, int K);
+/* dw[N,K] = dy[M,N]^T . x[M,K];  db[N] = column sums of dy (db may be NULL) */
+int pa2d_gemm_bwd_weight(const float* dy, long long lddy, const float* x, long long ldx, float* dw, float* db,
+                         void* ws, size_t ws_bytes, int M, int N, int K, pa2d_stream_t stream);
+
+/* ---- in_project_x / in_project_fx: two Conv2d(C, C, 3, 1, 1) on the same input,
+ * Physics_Attention.py:74-75,91-97, as ONE implicit GEMM on the NHWC ([B,N,C]) tensor.
+ * out[B*H*W, 2C] = [x_mid | fx_mid] (heads are channel groups h*D..h*D+D-1 of each half).
+ * Weights in the checkpoint layout [C_out, C_in, 3, 3].  Requires C % 16 == 0. */
+size_t pa2d_conv3x3x2_workspace(int B, int H, int W, int C);
+int pa2d_conv3x3x2_fwd(const float* xn, const float* wx, const float* bx, const float* wf, const float* bf,
+                       float* out, float* bias2_ws /* 2C floats */, void* ws, size_t ws_bytes, int B, int H,
+                       int W, int C, pa2d_stream_t stream);
+/* dxn may be NULL (input needs no gradient) */
+int pa2d_conv3x3x2_bwd(const float* dout, const float* xn, const float* wx, const float* wf, float* dxn,
+                       float* dwx, float* dbx, float* dwf, float* dbf, float* dbias2_ws /* 2C floats */,
+                       void* ws, size_t ws_bytes, int B, int H, int W, int C, pa2d_stream_t stream);
+
+/* ---- slice: softmax((x_mid . Ws^T + bs) / clamp(temperature, .1, 5)) and the weighted scatter of
+ * N points into M tokens, Physics_Attention.py:98-101.  Emits per-chunk partial sums
+ * spart [B,heads,nchunk,M,D] and npart [B,heads,nchunk,M] (npart NULL = skip), nchunk =
+ * pa2d_slice_nchunk(B,N,heads); `v` is fx_mid in the forward and dY in backward phase A.
+ * D in {8,16,32,64}, M <= 128. */
+int pa2d_slice_nchunk(int B, int N, int heads);
+int pa2d_slice_scatter(const float* xm, long long ldx, const float* v, long long ldv, const float* ws,
+                       const float* bs, const float* temperature, float* spart, float* npart, int B, int N,
+                       int heads, int D, int M, pa2d_stream_t stream);
+
+/* ---- token attention among the M slice tokens of each (batch, head): normalisation by
+ * (slice_norm + 1e-5), to_q/to_k/to_v, softmax(q k^T D^-0.5), attn.v — Physics_Attention.py:102-111.
+ * Outputs s (raw sums), nrm, o (out_slice_token), all [B*heads, M, (D)]. */
+size_t pa2d_token_attn_lds_bytes(int M, int D, int backward);
+int pa2d_token_attn_fwd(const float* spart, const float* npart, const float* wq, const float* wk,
+                        const float* wv, float* s, float* nrm, float* o, int BH, int nchunk, int M, int D,
+                        pa2d_stream_t stream);
+size_t pa2d_token_attn_bwd_workspace(int BH, int D);
+int pa2d_token_attn_bwd(const float* s, const float* nrm, const float* wq, const float* wk, const float* wv,
+                        const float* dopart, float* ds, float* dn, float* dwq, float* dwk, float* dwv, void* ws,
+                        size_t ws_bytes, int BH, int nchunk, int M, int D, pa2d_stream_t stream);
+
+/* ---- de-slice: out_x = slice_weights . out_slice_token, written directly as [B,N,(h d)]
+ * (Physics_Attention.py:116-117); slice weights are recomputed from x_mid, never stored. */
+int pa2d_deslice_fwd(const float* xm, long long ldx, const float* o, const float* ws, const float* bs,
+                     const float* temperature, float* y, long long ldy, int B, int N, int heads, int D, int M,
+                     pa2d_stream_t stream);
+
+/* ---- backward of slice + de-slice w.r.t. the points (autograd of
+ * Physics_Attention.py:98-101,116): given dY, O, dS, dn produces dx_mid, dfx_mid and the fully
+ * reduced dWs [M,D], dbs [M], dtemperature [heads] (clamp mask applied). */
+size_t pa2d_slice_bwd_workspace(int B, int N, int heads, int D, int M);
+int pa2d_slice_bwd_points(const float* xm, long long ldx, const float* fm, long long ldf, const float* dy,
+                          long long lddy, const float* ws, const float* bs, const float* temperature,
+                          const float* o, const float* ds, const float* dn, float* dxm, long long lddx,
+                          float* dfm, long long lddf, float* dws, float* dbs, float* dtemperature, void* ws_buf,
+                          size_t ws_bytes, int B, int N, int heads, int D, int M, pa2d_stream_t stream);
+
+/* ---- output head mlp2 = nn.Linear(C, out_dim), out_dim <= 8 (…_2D.py:66,73) */
+int pa2d_head_fwd(const float* xn, const float* w, const float* b, float* y, int rows, int C, int out_dim,
+                  pa2d_stream_t stream);
+size_t pa2d_head_bwd_workspace(int rows, int C, int out_dim);
+int pa2d_head_bwd(const float* dy, const float* xn, const float* w, float* dxn, float* dw, float* db, void* ws,
+                  size_t ws_bytes, int rows, int C, int out_dim, pa2d_stream_t stream);
+
+/* ---- elementwise out = dy * act'(pre): backward of the activation of a generic Linear+act layer
+ * (MLP hidden layers with n_layers > 0, …_2D.py:28,32-36; not used by the NS/Darcy configurations) */
+int pa2d_act_bwd(const float* dy, const float* pre, float* out, long long n, int act, pa2d_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PA2D_H */

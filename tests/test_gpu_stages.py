@@ -1,0 +1,185 @@
+"""Stage-by-stage parity of the HIP kernels (called through the libpa2d C ABI via ops.py) against
+the CPU oracle on identical seeded inputs.  fp32 tolerances: the oracle is evaluated in fp64, the
+kernels in fp32 -> rel-L2 <= 2e-6 for forward stages, <= 1e-5 for gradients (SURVEY §8c calibrates
+the reference's own fp32-vs-fp64 error at 1e-6 / 3e-7..2.5e-4)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = 3e-6
+BWD_TOL = 2e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+def _r(rng, *shape, scale=1.0):
+    return torch.from_numpy((rng.standard_normal(shape) * scale).astype(np.float32))
+
+
+@pytest.mark.parametrize("rows,C", [(7, 32), (300, 64), (4096, 256), (1000, 1024)])
+def test_layernorm(dev, rows, C):
+    from transformerbasednavierstokesolver_amd import ops
+    from oracle import transolver_oracle as orc
+    rng = np.random.default_rng(rows + C)
+    x, g, b, dy, dres = _r(rng, rows, C) * 2 + 0.5, 1 + 0.1 * _r(rng, C), 0.1 * _r(rng, C), _r(rng, rows, C), _r(rng, rows, C)
+    xd = x.double().requires_grad_(True)
+    gd, bd = g.double().requires_grad_(True), b.double().requires_grad_(True)
+    yo = orc.layer_norm(xd, gd, bd)
+    yo.backward(dy.double())
+    y, mean, rstd = ops.layernorm_fwd(x.to(dev), g.to(dev), b.to(dev))
+    assert rel_l2(y, yo) < FWD_TOL
+    dx, dg, db = ops.layernorm_bwd(dy.to(dev), x.to(dev), mean, rstd, g.to(dev), dres.to(dev))
+    assert rel_l2(dx, xd.grad + dres.double()) < BWD_TOL
+    assert rel_l2(dg, gd.grad) < BWD_TOL and rel_l2(db, bd.grad) < BWD_TOL
+
+
+@pytest.mark.parametrize("M,N,K,act", [(60, 32, 12, "gelu"), (257, 64, 76, "silu"), (4096, 256, 256, "gelu"),
+                                       (1000, 512, 76, None), (333, 96, 200, "tanh"), (130, 8, 64, None)])
+def test_linear(dev, M, N, K, act):
+    from transformerbasednavierstokesolver_amd import ops
+    from oracle import transolver_oracle as orc
+    rng = np.random.default_rng(M + N + K)
+    x, w, b, res = _r(rng, M, K), _r(rng, N, K, scale=K ** -0.5), 0.1 * _r(rng, N), _r(rng, M, N)
+    dy = _r(rng, M, N)
+    xd, wd, bd = (t.double().requires_grad_(True) for t in (x, w, b))
+    pre = xd @ wd.t() + bd
+    yo = (orc._ACTS[act](pre) if act else pre) + res.double()
+    yo.backward(dy.double())
+    y, pre_k = ops.linear_fwd(x.to(dev), w.to(dev), b.to(dev), res=res.to(dev), act=act, want_pre=True)
+    assert rel_l2(y, yo) < FWD_TOL
+    assert rel_l2(pre_k, pre) < FWD_TOL
+    # backward pieces (the act' factor is applied by the NEXT bwd_data call's epilogue, tested below)
+    dwk, dbk = ops.linear_bwd_weight(dy.to(dev), x.to(dev))
+    dxk = ops.linear_bwd_data(dy.to(dev), w.to(dev))
+    if act is None:
+        assert rel_l2(dwk, wd.grad) < BWD_TOL and rel_l2(dbk, bd.grad) < BWD_TOL
+        assert rel_l2(dxk, xd.grad) < BWD_TOL
+    else:
+        # check the fused dact epilogue: dx = (dy . w) * act'(pre2) with an independent pre2 [M,K]
+        pre2 = _r(rng, M, K)
+        p2 = pre2.double().requires_grad_(True)
+        orc._ACTS[act](p2).backward(torch.ones(M, K, dtype=torch.float64))
+        want = (dy.double() @ w.double()) * p2.grad
+        got = ops.linear_bwd_data(dy.to(dev), w.to(dev), pre=pre2.to(dev), act=act)
+        assert rel_l2(got, want) < BWD_TOL
+        assert rel_l2(dwk, dy.double().t() @ x.double()) < BWD_TOL
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 6, 5, 32), (1, 64, 64, 64), (2, 64, 64, 256), (1, 21, 17, 128)])
+def test_conv3x3x2(dev, B, H, W, C):
+    from transformerbasednavierstokesolver_amd import ops
+    from oracle import transolver_oracle as orc
+    rng = np.random.default_rng(B * H + C)
+    N = H * W
+    xn = _r(rng, B, N, C)
+    wx, wf = _r(rng, C, C, 3, 3, scale=(9 * C) ** -0.5), _r(rng, C, C, 3, 3, scale=(9 * C) ** -0.5)
+    bx, bf = 0.1 * _r(rng, C), 0.1 * _r(rng, C)
+    dout = _r(rng, B, N, 2 * C)
+    xd, wxd, wfd, bxd, bfd = (t.double().requires_grad_(True) for t in (xn, wx, wf, bx, bf))
+    out_o = torch.cat([orc.conv3x3(xd, wxd, bxd, H, W), orc.conv3x3(xd, wfd, bfd, H, W)], -1)
+    out_o.backward(dout.double())
+    out = ops.conv3x3x2_fwd(xn.to(dev), wx.to(dev), bx.to(dev), wf.to(dev), bf.to(dev), H, W)
+    assert rel_l2(out, out_o) < FWD_TOL
+    dxn, dwx, dbx, dwf, dbf = ops.conv3x3x2_bwd(dout.to(dev), xn.to(dev), wx.to(dev), wf.to(dev), H, W)
+    assert rel_l2(dxn, xd.grad) < BWD_TOL
+    assert rel_l2(dwx, wxd.grad) < BWD_TOL and rel_l2(dwf, wfd.grad) < BWD_TOL
+    assert rel_l2(dbx, bxd.grad) < BWD_TOL and rel_l2(dbf, bfd.grad) < BWD_TOL
+
+
+SLICE_CASES = [  # B, N, heads, D, M
+    (2, 30, 4, 8, 12),      # tiny, ragged points (30 % 16 != 0), M not a multiple of 16
+    (1, 4096, 8, 8, 32),    # shipped-checkpoint geometry (C=64)
+    (2, 4096, 8, 32, 64),   # NS benchmark geometry (C=256)
+    (1, 1000, 8, 16, 128),  # Darcy-like geometry (D=16, M=128), ragged N
+    (1, 200, 2, 64, 20),
+]
+
+
+def _slice_inputs(B, N, heads, D, M, seed):
+    rng = np.random.default_rng(seed)
+    C = heads * D
+    xf = _r(rng, B, N, 2 * C)
+    ws, bs = _r(rng, M, D, scale=D ** -0.5), 0.3 * _r(rng, M)
+    temp = torch.tensor(np.resize(np.array([0.03, 0.5, 7.0, 0.25, 1.5, 0.1, 5.0, 0.8], dtype=np.float32), heads))
+    wq, wk, wv = (_r(rng, D, D, scale=1.5 * D ** -0.5) for _ in range(3))
+    dy = _r(rng, B, N, C)
+    return xf, ws, bs, temp, wq, wk, wv, dy
+
+
+@pytest.mark.parametrize("B,N,heads,D,M", SLICE_CASES)
+def test_slice_token_deslice_forward(dev, B, N, heads, D, M):
+    from transformerbasednavierstokesolver_amd import ops
+    from oracle import transolver_oracle as orc
+    C = heads * D
+    xf, ws, bs, temp, wq, wk, wv, _ = _slice_inputs(B, N, heads, D, M, B + N + M)
+    xfd = xf.double()
+    w, norm, s, tok = orc.slice_tokens(xfd[..., :C], xfd[..., C:], ws.double(), bs.double(), temp.double(), heads)
+    o = orc.token_attention(tok, wq.double(), wk.double(), wv.double())
+    y = orc.deslice(w, o)
+    g = lambda t: t.to(dev)
+    spart, npart = ops.slice_scatter(g(xf), 2 * C, 0, g(xf), 2 * C, C, g(ws), g(bs), g(temp), B, N, heads, D, M)
+    assert rel_l2(spart.sum(1).view(B, heads, M, D), s) < FWD_TOL
+    assert rel_l2(npart.sum(1).view(B, heads, M), norm) < FWD_TOL
+    sk, nk, ok = ops.token_attn_fwd(spart, npart, g(wq), g(wk), g(wv))
+    assert rel_l2(sk.view(B, heads, M, D), s) < FWD_TOL and rel_l2(nk.view(B, heads, M), norm) < FWD_TOL
+    assert rel_l2(ok.view(B, heads, M, D), o) < 2e-5
+    # de-slice checked with the ORACLE's tokens so that errors do not compound
+    yk = ops.deslice_fwd(g(xf), 2 * C, 0, g(o.float().reshape(B * heads, M, D).contiguous()), g(ws), g(bs), g(temp),
+                         B, N, heads, D, M)
+    assert rel_l2(yk, y) < FWD_TOL
+
+
+@pytest.mark.parametrize("B,N,heads,D,M", SLICE_CASES)
+def test_slice_core_backward(dev, B, N, heads, D, M):
+    from transformerbasednavierstokesolver_amd import ops
+    from oracle import transolver_oracle as orc
+    C = heads * D
+    xf, ws, bs, temp, wq, wk, wv, dy = _slice_inputs(B, N, heads, D, M, 7 * B + N + M)
+    d = lambda t: t.double()
+    ref = orc.slice_core_backward(d(xf[..., :C]), d(xf[..., C:]), d(dy), d(ws), d(bs), d(temp), d(wq), d(wk), d(wv), heads)
+    g = lambda t: t.to(dev).contiguous()
+    # forward state
+    spart, npart = ops.slice_scatter(g(xf), 2 * C, 0, g(xf), 2 * C, C, g(ws), g(bs), g(temp), B, N, heads, D, M)
+    s, nrm, o = ops.token_attn_fwd(spart, npart, g(wq), g(wk), g(wv))
+    # phase A: dO partials
+    dopart, _ = ops.slice_scatter(g(xf), 2 * C, 0, g(dy), C, 0, g(ws), g(bs), g(temp), B, N, heads, D, M, want_norm=False)
+    assert rel_l2(dopart.sum(1).view(B, heads, M, D), ref["do"]) < BWD_TOL
+    ds, dn, dwq, dwk, dwv = ops.token_attn_bwd(s, nrm, g(wq), g(wk), g(wv), dopart)
+    assert rel_l2(ds.view(B, heads, M, D), ref["ds"]) < 5e-5
+    assert rel_l2(dn.view(B, heads, M), ref["dn"]) < 5e-5
+    assert rel_l2(dwq, ref["dwq"]) < 5e-5 and rel_l2(dwk, ref["dwk"]) < 5e-5 and rel_l2(dwv, ref["dwv"]) < 5e-5
+    # phase C with the oracle's dS / dn / O so that errors do not compound
+    f32 = lambda t, *shape: g(t.float().reshape(*shape))
+    o_ref = orc.token_attention(orc.slice_tokens(d(xf[..., :C]), d(xf[..., C:]), d(ws), d(bs), d(temp), heads)[3],
+                                d(wq), d(wk), d(wv))
+    dxf, dws, dbs, dtemp = ops.slice_bwd_points(g(xf), g(dy), g(ws), g(bs), g(temp), f32(o_ref, B * heads, M, D),
+                                                f32(ref["ds"], B * heads, M, D), f32(ref["dn"], B * heads, M),
+                                                B, N, heads, D, M)
+    assert rel_l2(dxf[..., :C], ref["dxm"]) < BWD_TOL
+    assert rel_l2(dxf[..., C:], ref["dfm"]) < BWD_TOL
+    assert rel_l2(dws, ref["dws"]) < BWD_TOL and rel_l2(dbs, ref["dbs"]) < BWD_TOL
+    assert rel_l2(dtemp, ref["dtemperature"].reshape(heads)) < BWD_TOL
+    # clamp mask: heads whose raw temperature is outside [0.1, 5] get exactly zero gradient
+    outside = (temp < 0.1) | (temp > 5.0)
+    assert torch.all(dtemp.cpu()[outside] == 0)
+
+
+@pytest.mark.parametrize("rows,C,O", [(30, 32, 2), (4096, 256, 1), (500, 64, 5)])
+def test_head(dev, rows, C, O):
+    from transformerbasednavierstokesolver_amd import ops
+    rng = np.random.default_rng(rows + O)
+    x, w, b, dy = _r(rng, rows, C), _r(rng, O, C, scale=C ** -0.5), 0.1 * _r(rng, O), _r(rng, rows, O)
+    g = lambda t: t.to(dev)
+    y = ops.head_fwd(g(x), g(w), g(b))
+    assert rel_l2(y, x.double() @ w.double().t() + b.double()) < FWD_TOL
+    dx, dw, db = ops.head_bwd(g(dy), g(x), g(w))
+    assert rel_l2(dx, dy.double() @ w.double()) < BWD_TOL
+    assert rel_l2(dw, dy.double().t() @ x.double()) < BWD_TOL
+    assert rel_l2(db, dy.double().sum(0)) < BWD_TOL

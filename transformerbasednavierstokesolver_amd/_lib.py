@@ -1,0 +1,80 @@
+"""ctypes binding of libpa2d.so (include/pa2d.h).  The library is built in-tree by
+`__graft_entry__.build()` / `make -C transformerbasednavierstokesolver_amd/csrc`.
+
+There is deliberately NO fallback: if the shared object is missing or a symbol cannot be bound the
+import of the compute path raises, and every non-zero return code becomes a RuntimeError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libpa2d.so")
+
+_f = C.c_void_p      # const float* / float* (device pointers travel as integers)
+_i = C.c_int
+_ll = C.c_longlong
+_sz = C.c_size_t
+_st = C.c_void_p     # hipStream_t
+
+# name -> (restype, argtypes); mirrors include/pa2d.h one to one
+SIGNATURES = {
+    "pa2d_version": (C.c_char_p, []),
+    "pa2d_layernorm_fwd": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, C.c_float, _st]),
+    "pa2d_layernorm_bwd_workspace": (_sz, [_i, _i]),
+    "pa2d_layernorm_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _sz, _i, _i, _st]),
+    "pa2d_gemm_bias_act_fwd": (_i, [_f, _ll, _f, _ll, _f, _f, _ll, _f, _ll, _f, _ll, _i, _i, _i, _i, _st]),
+    "pa2d_gemm_bwd_data": (_i, [_f, _ll, _f, _ll, _f, _ll, _i, _f, _ll, _f, _i, _i, _i, _st]),
+    "pa2d_gemm_bwd_weight_workspace": (_sz, [_i, _i, _i]),
+    "pa2d_gemm_bwd_weight": (_i, [_f, _ll, _f, _ll, _f, _f, _f, _sz, _i, _i, _i, _st]),
+    "pa2d_conv3x3x2_workspace": (_sz, [_i, _i, _i, _i]),
+    "pa2d_conv3x3x2_fwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _i, _st]),
+    "pa2d_conv3x3x2_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _i, _st]),
+    "pa2d_slice_nchunk": (_i, [_i, _i, _i]),
+    "pa2d_slice_scatter": (_i, [_f, _ll, _f, _ll, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _st]),
+    "pa2d_token_attn_lds_bytes": (_sz, [_i, _i, _i]),
+    "pa2d_token_attn_fwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _st]),
+    "pa2d_token_attn_bwd_workspace": (_sz, [_i, _i]),
+    "pa2d_token_attn_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _i, _st]),
+    "pa2d_deslice_fwd": (_i, [_f, _ll, _f, _f, _f, _f, _f, _ll, _i, _i, _i, _i, _i, _st]),
+    "pa2d_slice_bwd_workspace": (_sz, [_i, _i, _i, _i, _i]),
+    "pa2d_slice_bwd_points": (_i, [_f, _ll, _f, _ll, _f, _ll, _f, _f, _f, _f, _f, _f, _f, _ll, _f, _ll, _f, _f, _f,
+                                   _f, _sz, _i, _i, _i, _i, _i, _st]),
+    "pa2d_head_fwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _st]),
+    "pa2d_head_bwd_workspace": (_sz, [_i, _i, _i]),
+    "pa2d_head_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _st]),
+    "pa2d_act_bwd": (_i, [_f, _f, _f, _ll, _i, _st]),
+}
+
+ERRORS = {1001: "PA2D_ERR_ARG (alignment/shape contract)", 1002: "PA2D_ERR_UNSUPPORTED (size outside kernel grid)",
+          1003: "PA2D_ERR_WORKSPACE (workspace too small)"}
+
+_lib = None
+
+
+class NativeLibraryMissing(RuntimeError):
+    pass
+
+
+def load():
+    """Load libpa2d.so once and bind every symbol of include/pa2d.h; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryMissing(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C transformerbasednavierstokesolver_amd/csrc`). There is no CPU/PyTorch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise RuntimeError(f"libpa2d: {what} failed with code {rc} ({ERRORS.get(rc, 'hipError_t')})")

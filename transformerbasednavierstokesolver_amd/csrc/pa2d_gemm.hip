@@ -1,0 +1,579 @@
+// fp32 MFMA GEMM engine for the dense part of the Transolver block (gfx950 / CDNA4).
+//
+// Two kernels cover every dense contraction of the hot path (SURVEY.md §2b rows K1/K5 and their
+// backward):
+//
+//   gemm_kc : C[M,N] = epi(A[M,K] . B[N,K]^T)            both operands K-contiguous in memory.
+//             A may be an implicit im2col view of an NHWC image (3x3, pad 1): the conv of
+//             Physics_Attention.py:94,96 and its data-gradient run as one implicit GEMM without
+//             ever materialising the patches.  Used for linear fwd / bwd-data, conv fwd / bwd-data.
+//   gemm_mc : S[i,j]  = sum_m A[m,i] . B[m,j]             contraction over the ROW index of both
+//             operands (weight gradients: dW = dY^T X), split over workgroups along m; partial
+//             slabs are summed by reduce_slabs (deterministic, no float atomics).  B may be the
+//             im2col view (conv weight gradient).
+//
+// Both use v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD = 157 TFLOP/s chip peak), a
+// 128x128x16 (or 128x64 / 64x64) workgroup tile, 4 waves = one per SIMD, two workgroups per CU so
+// one workgroup's global->LDS staging hides behind the other's MFMAs, register-staged double
+// buffering with one barrier per K-step.
+//
+// Fragment maps (cdna_hip_programming.md §3): A operand lane l holds A[i=l&31][k=l>>5], B operand
+// holds B[k=l>>5][j=l&31]; C/D: col = l&31, row = (r&3) + 8*(r>>2) + 4*(l>>5).
+// In gemm_kc each lane fetches 4 consecutive k with one ds_read_b128 and feeds MFMA step t with
+// element t of both fragments, i.e. MFMA-k {0,1} <-> real k {8kk+t, 8kk+4+t}: any permutation of k
+// is fine as long as A and B use the same one.
+#include "pa2d_internal.h"
+
+#define EPI_ACT 1        // out = act(acc + bias)
+#define EPI_STORE_PRE 2  // aux = acc + bias   (pre-activation, saved for backward)
+#define EPI_MUL_DACT 4   // out = acc * act'(aux)
+
+struct KCParams {
+    const float* A; long long lda;
+    const float* B; long long ldb;
+    float* C; long long ldc;
+    const float* bias;
+    const float* res; long long ldres;
+    float* aux; long long ldaux;
+    int M, N, K;
+    int act, epi;
+    int H, W, Cin;   // im2col view: A = image [B,H,W,Cin] with pixel pitch lda, K = 9*Cin
+};
+
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool IM2COL>
+__global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KCParams p) {
+    constexpr int BK = 16, PITCH = BK + 4;
+    constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
+    constexpr int A_IT = BM / 64, B_IT = BN / 64;
+    static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1, "tile");
+    __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * PITCH];
+    float* const As = smem;
+    float* const Bs = smem + 2 * BM * PITCH;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    // XCD-aware map: blocks b, b+8, ... share an XCD (round-robin dispatch), so give the tiles_n
+    // column tiles of one row tile (same A panel) to ids congruent mod 8.
+    const int group = blockIdx.x / (8 * tiles_n);
+    const int loc = blockIdx.x - group * 8 * tiles_n;
+    const int tile_m = group * 8 + (loc & 7);
+    const int tile_n = loc >> 3;
+    if (tile_m >= tiles_m) return;
+
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int lr = tid >> 2, lq = tid & 3;
+
+    const float* a_base[A_IT];
+    bool a_ok[A_IT];
+    int a_y[A_IT], a_x[A_IT];
+#pragma unroll
+    for (int s = 0; s < A_IT; ++s) {
+        const int gm = tile_m * BM + lr + 64 * s;
+        a_ok[s] = gm < p.M;
+        a_base[s] = p.A + (size_t)(a_ok[s] ? gm : 0) * p.lda;
+        if (IM2COL) {
+            const int n = gm % (p.H * p.W);
+            a_y[s] = n / p.W;
+            a_x[s] = n - a_y[s] * p.W;
+        } else {
+            a_y[s] = a_x[s] = 0;
+        }
+    }
+    const float* b_base[B_IT];
+    bool b_ok[B_IT];
+#pragma unroll
+    for (int s = 0; s < B_IT; ++s) {
+        const int gn = tile_n * BN + lr + 64 * s;
+        b_ok[s] = gn < p.N;
+        b_base[s] = p.B + (size_t)(b_ok[s] ? gn : 0) * p.ldb;
+    }
+
+    float4 ra[A_IT], rb[B_IT];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_chunk = [&](int kc) {
+        const int k0 = kc * BK;
+        const int k = k0 + lq * 4;
+        const bool kin = k < p.K;
+        if (IM2COL) {
+            const int tap = k0 / p.Cin;
+            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+            const long long off = (long long)(dy * p.W + dx) * p.lda + (k - tap * p.Cin);
+#pragma unroll
+            for (int s = 0; s < A_IT; ++s) {
+                const bool ok = a_ok[s] && kin && (unsigned)(a_y[s] + dy) < (unsigned)p.H &&
+                                (unsigned)(a_x[s] + dx) < (unsigned)p.W;
+                ra[s] = ok ? *reinterpret_cast<const float4*>(a_base[s] + off) : zero4;
+            }
+        } else {
+#pragma unroll
+            for (int s = 0; s < A_IT; ++s)
+                ra[s] = (a_ok[s] && kin) ? *reinterpret_cast<const float4*>(a_base[s] + k) : zero4;
+        }
+#pragma unroll
+        for (int s = 0; s < B_IT; ++s)
+            rb[s] = (b_ok[s] && kin) ? *reinterpret_cast<const float4*>(b_base[s] + k) : zero4;
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int s = 0; s < A_IT; ++s)
+            *reinterpret_cast<float4*>(As + buf * BM * PITCH + (lr + 64 * s) * PITCH + lq * 4) = ra[s];
+#pragma unroll
+        for (int s = 0; s < B_IT; ++s)
+            *reinterpret_cast<float4*>(Bs + buf * BN * PITCH + (lr + 64 * s) * PITCH + lq * 4) = rb[s];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (p.K + BK - 1) / BK;
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+    const int frag_off = (lane & 31) * PITCH + (lane >> 5) * 4;
+    for (int kc = 0; kc < nk; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < nk) load_chunk(kc + 1);
+        const float* a_s = As + buf * BM * PITCH + wm * WM * PITCH + frag_off;
+        const float* b_s = Bs + buf * BN * PITCH + wn * WN * PITCH + frag_off;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            float4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const float4*>(a_s + i * 32 * PITCH + kk * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const float4*>(b_s + j * 32 * PITCH + kk * 8);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (kc + 1 < nk) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    // epilogue: lanes 0-31 of register r write 32 consecutive floats of one row (128 B)
+    const int col0 = tile_n * BN + wn * WN + (lane & 31);
+    const int row0 = tile_m * BM + wm * WM + 4 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = col0 + j * 32;
+        if (col >= p.N) continue;
+        const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                if (row >= p.M) continue;
+                float v = acc[i][j][r] + bv;
+                if (p.epi & EPI_STORE_PRE) p.aux[(size_t)row * p.ldaux + col] = v;
+                if (p.epi & EPI_ACT) v = act_fwd(p.act, v);
+                if (p.epi & EPI_MUL_DACT) v *= act_bwd(p.act, p.aux[(size_t)row * p.ldaux + col]);
+                if (p.res) v += p.res[(size_t)row * p.ldres + col];
+                p.C[(size_t)row * p.ldc + col] = v;
+            }
+    }
+}
+
+static int launch_kc(const KCParams& p, bool im2col, hipStream_t st) {
+    if (p.M <= 0 || p.N <= 0 || p.K <= 0) return PA2D_OK;
+    if ((p.K & 3) || (p.lda & 3) || (p.ldb & 3)) return PA2D_ERR_ARG;
+    if (im2col && ((p.Cin & 15) || p.K != 9 * p.Cin)) return PA2D_ERR_UNSUPPORTED;
+    const int tiles_m = ceil_div(p.M, 128);
+    if (p.N > 64) {
+        const int tiles_n = ceil_div(p.N, 128);
+        const dim3 grid(ceil_div(tiles_m, 8) * 8 * tiles_n);
+        if (im2col) hipLaunchKernelGGL((gemm_kc_kernel<128, 128, 2, 2, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_kc_kernel<128, 128, 2, 2, false>), grid, dim3(256), 0, st, p);
+    } else {
+        const int tiles_n = ceil_div(p.N, 64);
+        const dim3 grid(ceil_div(tiles_m, 8) * 8 * tiles_n);
+        if (im2col) hipLaunchKernelGGL((gemm_kc_kernel<128, 64, 4, 1, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_kc_kernel<128, 64, 4, 1, false>), grid, dim3(256), 0, st, p);
+    }
+    PA2D_CHECK_LAUNCH();
+    return PA2D_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+struct MCParams {
+    const float* A; long long lda; int Mi;
+    const float* B; long long ldb; int Nj;
+    float* slab;
+    int Mk, chunks_per_split;
+    int H, W, Cin;   // im2col view of B: image [B,H,W,Cin] with pixel pitch ldb, j = tap*Cin + ci
+};
+
+template <int BM, int BN, bool IM2COL>
+__global__ __launch_bounds__(256, 2) void gemm_mc_kernel(const MCParams p) {
+    constexpr int BK = 16;
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int A_TPR = BM / 4, A_RPP = 256 / A_TPR, A_IT = BK / A_RPP;
+    constexpr int B_TPR = BN / 4, B_RPP = 256 / B_TPR, B_IT = BK / B_RPP;
+    static_assert(TM >= 1 && TN >= 1 && A_IT >= 1 && B_IT >= 1, "tile");
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * (BM + BN)];
+    float* const As = smem;
+    float* const Bs = smem + 2 * BK * BM;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_i = (p.Mi + BM - 1) / BM, tiles_j = (p.Nj + BN - 1) / BN;
+    const int tj = blockIdx.x % tiles_j;
+    const int ti = (blockIdx.x / tiles_j) % tiles_i;
+    const int split = blockIdx.x / (tiles_i * tiles_j);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int total_chunks = (p.Mk + BK - 1) / BK;
+    const int c_begin = split * p.chunks_per_split;
+    const int c_end = min(total_chunks, c_begin + p.chunks_per_split);
+
+    const int a_r = tid / A_TPR, a_c = (tid % A_TPR) * 4;
+    const int b_r = tid / B_TPR, b_c = (tid % B_TPR) * 4;
+    const int gi = ti * BM + a_c;
+    const int gj = tj * BN + b_c;
+    const bool a_col_ok = gi < p.Mi, b_col_ok = gj < p.Nj;
+    int tap_dy = 0, tap_dx = 0, ci = 0;
+    if (IM2COL && b_col_ok) {
+        const int tap = gj / p.Cin;
+        ci = gj - tap * p.Cin;
+        tap_dy = tap / 3 - 1;
+        tap_dx = tap - (tap / 3) * 3 - 1;
+    }
+    const int HW = p.H * p.W;
+
+    float4 ra[A_IT], rb[B_IT];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_chunk = [&](int c) {
+        const int m0 = c * BK;
+#pragma unroll
+        for (int s = 0; s < A_IT; ++s) {
+            const int m = m0 + a_r + s * A_RPP;
+            ra[s] = (a_col_ok && m < p.Mk) ? *reinterpret_cast<const float4*>(p.A + (size_t)m * p.lda + gi) : zero4;
+        }
+#pragma unroll
+        for (int s = 0; s < B_IT; ++s) {
+            const int m = m0 + b_r + s * B_RPP;
+            bool ok = b_col_ok && m < p.Mk;
+            if (IM2COL) {
+                const int n = m % HW;
+                const int y = n / p.W, x = n - y * p.W;
+                ok = ok && (unsigned)(y + tap_dy) < (unsigned)p.H && (unsigned)(x + tap_dx) < (unsigned)p.W;
+                const long long off = ((long long)m + tap_dy * p.W + tap_dx) * p.ldb + ci;
+                rb[s] = ok ? *reinterpret_cast<const float4*>(p.B + off) : zero4;
+            } else {
+                rb[s] = ok ? *reinterpret_cast<const float4*>(p.B + (size_t)m * p.ldb + gj) : zero4;
+            }
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int s = 0; s < A_IT; ++s)
+            *reinterpret_cast<float4*>(As + buf * BK * BM + (a_r + s * A_RPP) * BM + a_c) = ra[s];
+#pragma unroll
+        for (int s = 0; s < B_IT; ++s)
+            *reinterpret_cast<float4*>(Bs + buf * BK * BN + (b_r + s * B_RPP) * BN + b_c) = rb[s];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (c_begin < c_end) {
+        load_chunk(c_begin);
+        store_chunk(0);
+    }
+    __syncthreads();
+    const int li = lane & 31, kh = lane >> 5;
+    for (int c = c_begin; c < c_end; ++c) {
+        const int buf = (c - c_begin) & 1;
+        if (c + 1 < c_end) load_chunk(c + 1);
+        const float* a_s = As + buf * BK * BM + kh * BM + wm * WM + li;
+        const float* b_s = Bs + buf * BK * BN + kh * BN + wn * WN + li;
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = a_s[kk * 2 * BM + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bf[j] = b_s[kk * 2 * BN + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (c + 1 < c_end) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    float* out = p.slab + (size_t)split * p.Mi * p.Nj;
+    const int col0 = tj * BN + wn * WN + (lane & 31);
+    const int row0 = ti * BM + wm * WM + 4 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = col0 + j * 32;
+        if (col >= p.Nj) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                if (row < p.Mi) out[(size_t)row * p.Nj + col] = acc[i][j][r];
+            }
+    }
+}
+
+struct MCPlan { int big; int splits; int chunks_per_split; size_t slab_floats; };
+
+static MCPlan plan_mc(int Mi, int Nj, int Mk) {
+    MCPlan pl;
+    pl.big = (Mi > 64 && Nj > 64) ? 1 : 0;
+    const int bm = pl.big ? 128 : 64;
+    const int tiles = ceil_div(Mi, bm) * ceil_div(Nj, bm);
+    const int total_chunks = ceil_div(Mk, 16);
+    int splits = ceil_div(1024, tiles);
+    const int max_splits = total_chunks / 8 > 0 ? total_chunks / 8 : 1;   // >= 8 chunks per split
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    pl.chunks_per_split = ceil_div(total_chunks, splits);
+    pl.splits = ceil_div(total_chunks, pl.chunks_per_split);
+    pl.slab_floats = (size_t)pl.splits * Mi * Nj;
+    return pl;
+}
+
+// out[idx] = sum_s slab[s][idx]; mode 1 additionally un-packs the conv weight gradient:
+// slab row-major [2C][9][Cin] -> dWx / dWf in the reference's [C_out][C_in][3][3] layout.
+__global__ void reduce_slabs_kernel(const float* __restrict__ slab, int nslab, long long count,
+                                    float* __restrict__ out, float* __restrict__ out2, int mode, int C, int Cin) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= count) return;
+    float s = 0.f;
+    for (int k = 0; k < nslab; ++k) s += slab[(size_t)k * count + idx];
+    if (mode == 0) {
+        out[idx] = s;
+    } else {
+        const int ci = (int)(idx % Cin);
+        const int tap = (int)((idx / Cin) % 9);
+        const int co = (int)(idx / ((long long)Cin * 9));
+        float* dst = co < C ? out : out2;
+        dst[((size_t)(co % C) * Cin + ci) * 9 + tap] = s;
+    }
+}
+
+static int launch_mc(const float* A, long long lda, int Mi, const float* B, long long ldb, int Nj, int Mk,
+                     bool im2col, int H, int W, int Cin, float* slab, const MCPlan& pl, hipStream_t st) {
+    if ((Mi & 3) || (Nj & 3) || (lda & 3) || (ldb & 3)) return PA2D_ERR_ARG;
+    if (im2col && (Cin & 3)) return PA2D_ERR_UNSUPPORTED;
+    MCParams p;
+    p.A = A; p.lda = lda; p.Mi = Mi; p.B = B; p.ldb = ldb; p.Nj = Nj; p.slab = slab; p.Mk = Mk;
+    p.chunks_per_split = pl.chunks_per_split; p.H = H; p.W = W; p.Cin = Cin;
+    const int bm = pl.big ? 128 : 64;
+    const dim3 grid(ceil_div(Mi, bm) * ceil_div(Nj, bm) * pl.splits);
+    if (pl.big) {
+        if (im2col) hipLaunchKernelGGL((gemm_mc_kernel<128, 128, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_mc_kernel<128, 128, false>), grid, dim3(256), 0, st, p);
+    } else {
+        if (im2col) hipLaunchKernelGGL((gemm_mc_kernel<64, 64, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_mc_kernel<64, 64, false>), grid, dim3(256), 0, st, p);
+    }
+    PA2D_CHECK_LAUNCH();
+    return PA2D_OK;
+}
+
+static int launch_reduce(const float* slab, int nslab, long long count, float* out, float* out2, int mode,
+                         int C, int Cin, hipStream_t st) {
+    const int threads = 256;
+    const dim3 grid((unsigned)ceil_div_ll(count, threads));
+    hipLaunchKernelGGL(reduce_slabs_kernel, grid, dim3(threads), 0, st, slab, nslab, count, out, out2, mode, C, Cin);
+    PA2D_CHECK_LAUNCH();
+    return PA2D_OK;
+}
+
+int pa2d_launch_reduce(const float* slab, int nslab, long long count, float* out, hipStream_t st) {
+    return launch_reduce(slab, nslab, count, out, nullptr, 0, 0, 0, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// column sums (bias gradients): partial[blk][n] over row blocks, then reduce_slabs.
+__global__ void colsum_partial_kernel(const float* __restrict__ X, long long ld, int M, int N, int rows_per_block,
+                                      float* __restrict__ partial) {
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(M, r0 + rows_per_block);
+    for (int c = threadIdx.x; c < N; c += blockDim.x) {
+        float s = 0.f;
+        for (int r = r0; r < r1; ++r) s += X[(size_t)r * ld + c];
+        partial[(size_t)blockIdx.x * N + c] = s;
+    }
+}
+
+static int colsum_blocks(int M) { int b = ceil_div(M, 128); return b > 1024 ? 1024 : (b < 1 ? 1 : b); }
+
+static int launch_colsum(const float* X, long long ld, int M, int N, float* out, float* partial, hipStream_t st) {
+    const int nb = colsum_blocks(M);
+    const int rpb = ceil_div(M, nb);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, st, X, ld, M, N, rpb, partial);
+    PA2D_CHECK_LAUNCH();
+    return launch_reduce(partial, nb, N, out, nullptr, 0, 0, 0, st);
+}
+
+// ---------------------------------------------------------------------------------------------
+// weight re-layouts (tiny; weights change every optimizer step so they are redone per call)
+// mode 0: plain transpose  dst[k][n] = src[n][k]                                  (linear bwd-data)
+// mode 1: conv fwd pack    dst[co'][tap][ci] = W_{co'<C ? x : f}[co][ci][tap]      ([2C][9*Cin])
+// mode 2: conv bwd pack    dst[ci][tap'][co'] = W_{..}[co][ci][8 - tap']           ([Cin][9*2C])
+__global__ void repack_kernel(const float* __restrict__ w0, const float* __restrict__ w1, float* __restrict__ dst,
+                              int mode, int N, int K, int C, int Cin) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (mode == 0) {
+        if (idx >= (long long)N * K) return;
+        const int n = (int)(idx % N), k = (int)(idx / N);
+        dst[idx] = w0[(size_t)n * K + k];
+    } else if (mode == 1) {
+        if (idx >= (long long)2 * C * 9 * Cin) return;
+        const int ci = (int)(idx % Cin);
+        const int tap = (int)((idx / Cin) % 9);
+        const int co = (int)(idx / ((long long)Cin * 9));
+        const float* src = co < C ? w0 : w1;
+        dst[idx] = src[((size_t)(co % C) * Cin + ci) * 9 + tap];
+    } else {
+        if (idx >= (long long)2 * C * 9 * Cin) return;
+        const int co = (int)(idx % (2 * C));
+        const int tap = (int)((idx / (2 * C)) % 9);
+        const int ci = (int)(idx / ((long long)2 * C * 9));
+        const float* src = co < C ? w0 : w1;
+        dst[idx] = src[((size_t)(co % C) * Cin + ci) * 9 + (8 - tap)];
+    }
+}
+
+static int launch_repack(const float* w0, const float* w1, float* dst, int mode, int N, int K, int C, int Cin,
+                         hipStream_t st) {
+    const long long count = mode == 0 ? (long long)N * K : (long long)2 * C * 9 * Cin;
+    hipLaunchKernelGGL(repack_kernel, dim3((unsigned)ceil_div_ll(count, 256)), dim3(256), 0, st, w0, w1, dst, mode,
+                       N, K, C, Cin);
+    PA2D_CHECK_LAUNCH();
+    return PA2D_OK;
+}
+
+// =============================================================================================
+// C ABI (declared in include/pa2d.h)
+extern "C" {
+
+int pa2d_gemm_bias_act_fwd(const float* x, long long ldx, const float* w, long long ldw, const float* bias,
+                           const float* res, long long ldres, float* y, long long ldy, float* pre, long long ldpre,
+                           int M, int N, int K, int act, hipStream_t st) {
+    KCParams p = {};
+    p.A = x; p.lda = ldx; p.B = w; p.ldb = ldw; p.C = y; p.ldc = ldy; p.bias = bias; p.res = res; p.ldres = ldres;
+    p.aux = pre; p.ldaux = ldpre; p.M = M; p.N = N; p.K = K; p.act = act;
+    p.epi = (act != ACT_NONE ? EPI_ACT : 0) | (pre ? EPI_STORE_PRE : 0);
+    return launch_kc(p, false, st);
+}
+
+// dx[M,K] = (dy[M,N] . w[N,K]) * act'(pre[M,K])   (pre may be NULL -> plain product)
+// wt_ws: K*N floats of scratch for the transposed weight.
+int pa2d_gemm_bwd_data(const float* dy, long long lddy, const float* w, long long ldw, const float* pre,
+                       long long ldpre, int act, float* dx, long long lddx, float* wt_ws, int M, int N, int K,
+                       hipStream_t st) {
+    if (ldw != K) return PA2D_ERR_ARG;
+    if (N & 3) return PA2D_ERR_ARG;
+    int rc = launch_repack(w, nullptr, wt_ws, 0, N, K, 0, 0, st);
+    if (rc) return rc;
+    KCParams p = {};
+    p.A = dy; p.lda = lddy; p.B = wt_ws; p.ldb = N; p.C = dx; p.ldc = lddx; p.M = M; p.N = K; p.K = N;
+    p.aux = const_cast<float*>(pre); p.ldaux = ldpre; p.act = act;
+    p.epi = (pre && act != ACT_NONE) ? EPI_MUL_DACT : 0;
+    return launch_kc(p, false, st);
+}
+
+size_t pa2d_gemm_bwd_weight_workspace(int M, int N, int K) {
+    const MCPlan pl = plan_mc(N, K, M);
+    size_t a = pl.slab_floats, b = (size_t)colsum_blocks(M) * N;
+    return (a > b ? a : b) * sizeof(float);
+}
+
+// dw[N,K] = dy[M,N]^T . x[M,K] ; db[N] = column sums of dy (db may be NULL)
+int pa2d_gemm_bwd_weight(const float* dy, long long lddy, const float* x, long long ldx, float* dw, float* db,
+                         void* ws, size_t ws_bytes, int M, int N, int K, hipStream_t st) {
+    if (ws_bytes < pa2d_gemm_bwd_weight_workspace(M, N, K)) return PA2D_ERR_WORKSPACE;
+    const MCPlan pl = plan_mc(N, K, M);
+    int rc = launch_mc(dy, lddy, N, x, ldx, K, M, false, 0, 0, 0, (float*)ws, pl, st);
+    if (rc) return rc;
+    rc = launch_reduce((const float*)ws, pl.splits, (long long)N * K, dw, nullptr, 0, 0, 0, st);
+    if (rc) return rc;
+    if (db) rc = launch_colsum(dy, lddy, M, N, db, (float*)ws, st);
+    return rc;
+}
+
+size_t pa2d_conv3x3x2_workspace(int B, int H, int W, int C) {
+    const size_t pack = (size_t)2 * C * 9 * C;
+    const MCPlan pl = plan_mc(2 * C, 9 * C, B * H * W);
+    size_t sl = pl.slab_floats, cs = (size_t)colsum_blocks(B * H * W) * 2 * C;
+    return (pack + (sl > cs ? sl : cs)) * sizeof(float);
+}
+
+// out[B*H*W, 2C] = [conv3x3(xn, wx) + bx | conv3x3(xn, wf) + bf]   (zero padding 1, NHWC)
+// Physics_Attention.py:94,96 — both projections read the same input, so they run as ONE implicit
+// GEMM [B*N, 9C] x [9C, 2C].
+int pa2d_conv3x3x2_fwd(const float* xn, const float* wx, const float* bx, const float* wf, const float* bf,
+                       float* out, float* bias2_ws /* 2C floats */, void* ws, size_t ws_bytes, int B, int H, int W,
+                       int C, hipStream_t st) {
+    if (ws_bytes < (size_t)2 * C * 9 * C * sizeof(float)) return PA2D_ERR_WORKSPACE;
+    float* pack = (float*)ws;
+    int rc = launch_repack(wx, wf, pack, 1, 0, 0, C, C, st);
+    if (rc) return rc;
+    hipError_t e = hipMemcpyAsync(bias2_ws, bx, C * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemcpyAsync(bias2_ws + C, bf, C * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return (int)e;
+    KCParams p = {};
+    p.A = xn; p.lda = C; p.B = pack; p.ldb = 9 * C; p.C = out; p.ldc = 2 * C; p.bias = bias2_ws;
+    p.M = B * H * W; p.N = 2 * C; p.K = 9 * C; p.H = H; p.W = W; p.Cin = C;
+    return launch_kc(p, true, st);
+}
+
+// dxn[B*N, C] (+= nothing; plain store), dwx/dwf [C,C,3,3], dbx/dbf [C]  from dout[B*N, 2C]
+int pa2d_conv3x3x2_bwd(const float* dout, const float* xn, const float* wx, const float* wf, float* dxn, float* dwx,
+                       float* dbx, float* dwf, float* dbf, float* dbias2_ws /* 2C floats */, void* ws,
+                       size_t ws_bytes, int B, int H, int W, int C, hipStream_t st) {
+    if (ws_bytes < pa2d_conv3x3x2_workspace(B, H, W, C)) return PA2D_ERR_WORKSPACE;
+    float* pack = (float*)ws;
+    float* scratch = pack + (size_t)2 * C * 9 * C;
+    const int M = B * H * W;
+    int rc;
+    if (dxn) {
+        rc = launch_repack(wx, wf, pack, 2, 0, 0, C, C, st);
+        if (rc) return rc;
+        KCParams p = {};
+        p.A = dout; p.lda = 2 * C; p.B = pack; p.ldb = 9 * 2 * C; p.C = dxn; p.ldc = C;
+        p.M = M; p.N = C; p.K = 9 * 2 * C; p.H = H; p.W = W; p.Cin = 2 * C;
+        rc = launch_kc(p, true, st);
+        if (rc) return rc;
+    }
+    const MCPlan pl = plan_mc(2 * C, 9 * C, M);
+    rc = launch_mc(dout, 2 * C, 2 * C, xn, C, 9 * C, M, true, H, W, C, scratch, pl, st);
+    if (rc) return rc;
+    rc = launch_reduce(scratch, pl.splits, (long long)2 * C * 9 * C, dwx, dwf, 1, C, C, st);
+    if (rc) return rc;
+    rc = launch_colsum(dout, 2 * C, M, 2 * C, dbias2_ws, scratch, st);
+    if (rc) return rc;
+    hipError_t e = hipMemcpyAsync(dbx, dbias2_ws, C * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemcpyAsync(dbf, dbias2_ws + C, C * sizeof(float), hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return (int)e;
+    return PA2D_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,68 @@
+// Internal helpers shared by the HIP translation units of libpa2d (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define PA2D_OK 0
+#define PA2D_ERR_ARG 1001
+#define PA2D_ERR_UNSUPPORTED 1002
+#define PA2D_ERR_WORKSPACE 1003
+
+#define PA2D_CHECK_LAUNCH()                         \
+    do {                                            \
+        hipError_t e__ = hipGetLastError();         \
+        if (e__ != hipSuccess) return (int)e__;     \
+    } while (0)
+
+// activation ids (ACTIVATION table of the reference, model/Transolver_Structured_Mesh_2D.py:9-10)
+enum { ACT_NONE = 0, ACT_GELU = 1, ACT_TANH = 2, ACT_SIGMOID = 3, ACT_RELU = 4, ACT_SOFTPLUS = 5,
+       ACT_ELU = 6, ACT_SILU = 7 };
+
+__device__ __forceinline__ float act_fwd(int id, float x) {
+    switch (id) {
+        case ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+        case ACT_TANH: return tanhf(x);
+        case ACT_SIGMOID: return 1.0f / (1.0f + expf(-x));
+        case ACT_RELU: return x > 0.f ? x : 0.f;
+        case ACT_SOFTPLUS: return x > 20.f ? x : log1pf(expf(x));
+        case ACT_ELU: return x > 0.f ? x : expm1f(x);
+        case ACT_SILU: return x / (1.0f + expf(-x));
+        default: return x;
+    }
+}
+
+// d act(x) / dx evaluated at the pre-activation x
+__device__ __forceinline__ float act_bwd(int id, float x) {
+    switch (id) {
+        case ACT_GELU: {
+            const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+            const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+            return cdf + x * pdf;
+        }
+        case ACT_TANH: { const float t = tanhf(x); return 1.0f - t * t; }
+        case ACT_SIGMOID: { const float s = 1.0f / (1.0f + expf(-x)); return s * (1.0f - s); }
+        case ACT_RELU: return x > 0.f ? 1.f : 0.f;
+        case ACT_SOFTPLUS: return x > 20.f ? 1.f : 1.0f / (1.0f + expf(-x));
+        case ACT_ELU: return x > 0.f ? 1.f : expf(x);
+        case ACT_SILU: { const float s = 1.0f / (1.0f + expf(-x)); return s * (1.0f + x * (1.0f - s)); }
+        default: return 1.f;
+    }
+}
+
+// 64-lane butterfly reductions (wave = 64 on gfx950)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+static inline long long ceil_div_ll(long long a, long long b) { return (a + b - 1) / b; }

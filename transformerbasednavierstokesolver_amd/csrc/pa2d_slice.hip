@@ -1,0 +1,690 @@
+// Slice / de-slice kernels of Physics-Attention (Physics_Attention.py:98-102,116) and their backward
+//  for gfx950.  The N x M slice-weight matrix W is never written to HBM: it
+// is recomputed from x_mid in every kernel that needs it and lives only in MFMA accumulators.
+//
+// All contractions run on v_mfma_f32_16x16x4_f32 (exact fp32).  Fragment maps: A operand lane l
+// holds A[i=l&15][k=l>>4], B operand B[k=l>>4][j=l&15], C/D element r is (row 4*(l>>4)+r, col l&15).
+// Two register layouts of a 16-point tile of W are used:
+//   N-layout (rows = points, cols = slices)   L  = X . Ws^T     -> softmax across 16 lanes (row of a
+//       16-lane group), accumulator register r of lane (m, kq) is W[point 4kq+r][m], i.e. exactly
+//       the A operand (i=m, k=point) of the scatter  S += W^T . F  (MFMA step r).
+//   T-layout (rows = slices, cols = points)   L^T = Ws . X^T    -> softmax in-lane (+2 shuffles),
+//       register (mt,r) of lane (pt, kq) is W[pt][16mt+4kq+r], i.e. the B operand (k=slice, j=pt)
+//       of  Y^T = O^T . W^T  (de-slice) and of the backward products dF^T, dX^T.
+// The k-order inside a contraction over d is permuted (lane (.,kq) loads VEC consecutive d and
+// feeds MFMA step t with element t): legal because A and B use the same permutation.
+// X / F / dY fragments are loaded straight from global memory (each element exactly once, 64-B
+// contiguous per point per instruction); no LDS in the forward kernels.
+#include "pa2d_internal.h"
+
+#define NEG_BIG (-1e30f)
+
+int pa2d_launch_reduce(const float* slab, int nslab, long long count, float* out, hipStream_t st);
+
+template <int D>
+struct SCfg {
+    static constexpr int VEC = D >= 16 ? 4 : 2;
+    static constexpr int NV = D / (4 * VEC);
+    static constexpr int KS = D / 4;          // MFMA steps of a contraction over d
+    static constexpr int DT = (D + 15) / 16;  // 16-wide tiles over d
+};
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 1, 64));
+    v = fmaxf(v, __shfl_xor(v, 2, 64));
+    v = fmaxf(v, __shfl_xor(v, 4, 64));
+    v = fmaxf(v, __shfl_xor(v, 8, 64));
+    return v;
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    return v;
+}
+__device__ __forceinline__ float kq_max(float v) {   // across the 4 lane groups l, l^16, l^32, l^48
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    v = fmaxf(v, __shfl_xor(v, 32, 64));
+    return v;
+}
+__device__ __forceinline__ float kq_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+__device__ __forceinline__ float clamp_tau(float t) { return fminf(fmaxf(t, 0.1f), 5.0f); }
+
+// fragment of a [16 rows][D] panel for a contraction over d: lane (row = l&15, kq = l>>4) gets
+// elements k(v,t) = 4*VEC*v + VEC*kq + t of its row.
+template <int D>
+__device__ __forceinline__ void load_kfrag(const float* row, bool valid, int kq, float (&f)[SCfg<D>::KS]) {
+    constexpr int VEC = SCfg<D>::VEC, NV = SCfg<D>::NV;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        if constexpr (VEC == 4) {
+            const float4 q = valid ? *reinterpret_cast<const float4*>(row + 16 * v + 4 * kq) : make_float4(0, 0, 0, 0);
+            f[4 * v + 0] = q.x; f[4 * v + 1] = q.y; f[4 * v + 2] = q.z; f[4 * v + 3] = q.w;
+        } else {
+            const float2 q = valid ? *reinterpret_cast<const float2*>(row + 8 * v + 2 * kq) : make_float2(0, 0);
+            f[2 * v + 0] = q.x; f[2 * v + 1] = q.y;
+        }
+    }
+}
+
+struct SliceParams {
+    const float* xm; long long ldx;     // x_mid rows: xm[(b*N+n)*ldx + h*D + d]
+    const float* v; long long ldv;      // values scattered (fx_mid forward, dY in backward phase A)
+    const float* ws; const float* bs; const float* temperature;   // [M,D], [M], [heads]
+    float* spart; float* npart;         // [B,heads,nchunk,M,D], [B,heads,nchunk,M] (npart may be null)
+    int B, N, heads, M, nchunk, ppc;    // ppc = points per chunk (multiple of 16)
+};
+
+// S_partial[m][d] = sum_{n in chunk} W[n][m] * V[n][d];  n_partial[m] = sum_n W[n][m]
+template <int D, int MT>
+__global__ __launch_bounds__(256) void slice_scatter_kernel(const SliceParams p) {
+    constexpr int KS = SCfg<D>::KS, DT = SCfg<D>::DT;
+    constexpr int MP = 16 * MT, DP = 16 * DT;
+    __shared__ float sbuf[MP * DP];
+    __shared__ float nbuf[MP];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
+    const int chunk = blockIdx.x % p.nchunk;
+    const int hh = (blockIdx.x / p.nchunk) % p.heads;
+    const int b = blockIdx.x / (p.nchunk * p.heads);
+    const float inv_tau = 1.0f / clamp_tau(p.temperature[hh]);
+
+    float wsf[MT][KS], bsv[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = 16 * mt + li;
+        load_kfrag<D>(p.ws + (size_t)(m < p.M ? m : 0) * D, m < p.M, kq, wsf[mt]);
+        bsv[mt] = m < p.M ? p.bs[m] : 0.f;
+    }
+    f32x4 sacc[MT][DT];
+    float nacc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        nacc[mt] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) sacc[mt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const int p_begin = chunk * p.ppc;
+    const int p_end = min(p.N, p_begin + p.ppc);
+    const size_t row0 = (size_t)b * p.N;
+    for (int g = p_begin + wave * 16; g < p_end; g += 64) {
+        float xf[KS];
+        {
+            const int pt = g + li;
+            const bool pv = pt < p_end;
+            load_kfrag<D>(p.xm + (row0 + (pv ? pt : p_begin)) * p.ldx + hh * D, pv, kq, xf);
+        }
+        f32x4 w[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            w[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) w[mt] = mfma16(xf[ks], wsf[mt][ks], w[mt]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float mx = NEG_BIG;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                float z = (w[mt][r] + bsv[mt]) * inv_tau;
+                if (16 * mt + li >= p.M) z = NEG_BIG;
+                w[mt][r] = z;
+                mx = fmaxf(mx, z);
+            }
+            mx = row16_max(mx);
+            float sm = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const float e = expf(w[mt][r] - mx);
+                w[mt][r] = e;
+                sm += e;
+            }
+            sm = row16_sum(sm);
+            const float inv = (g + 4 * kq + r) < p_end ? 1.0f / sm : 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                w[mt][r] *= inv;
+                nacc[mt] += w[mt][r];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int pr = g + 4 * kq + r;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int d = 16 * dt + li;
+                const float fv = (pr < p_end && d < D) ? p.v[(row0 + pr) * p.ldv + hh * D + d] : 0.f;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) sacc[mt][dt] = mfma16(w[mt][r], fv, sacc[mt][dt]);
+            }
+        }
+    }
+    // deterministic cross-wave reduction: waves add in order 0,1,2,3
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) nacc[mt] = kq_sum(nacc[mt]);
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wave == wv) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int idx = (16 * mt + 4 * kq + r) * DP + 16 * dt + li;
+                        sbuf[idx] = (wv == 0 ? 0.f : sbuf[idx]) + sacc[mt][dt][r];
+                    }
+                if (kq == 0) nbuf[16 * mt + li] = (wv == 0 ? 0.f : nbuf[16 * mt + li]) + nacc[mt];
+            }
+        }
+        __syncthreads();
+    }
+    float* so = p.spart + (size_t)blockIdx.x * p.M * D;
+    for (int i = tid; i < p.M * D; i += 256) so[i] = sbuf[(i / D) * DP + (i % D)];
+    if (p.npart)
+        for (int i = tid; i < p.M; i += 256) p.npart[(size_t)blockIdx.x * p.M + i] = nbuf[i];
+}
+
+struct DesliceParams {
+    const float* xm; long long ldx;
+    const float* o;                     // [B,heads,M,D]
+    const float* ws; const float* bs; const float* temperature;
+    float* y; long long ldy;            // y[(b*N+n)*ldy + h*D + d]
+    int B, N, heads, M, nchunk, ppc;
+};
+
+// Y[n][h*D+d] = sum_m W[n][m] * O[m][d]
+template <int D, int MT>
+__global__ __launch_bounds__(256) void deslice_kernel(const DesliceParams p) {
+    constexpr int KS = SCfg<D>::KS, DT = SCfg<D>::DT;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
+    const int chunk = blockIdx.x % p.nchunk;
+    const int hh = (blockIdx.x / p.nchunk) % p.heads;
+    const int b = blockIdx.x / (p.nchunk * p.heads);
+    const float inv_tau = 1.0f / clamp_tau(p.temperature[hh]);
+
+    float wsf[MT][KS], bst[MT][4], of[MT][4][DT];
+    const float* ob = p.o + (size_t)(b * p.heads + hh) * p.M * D;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int m = 16 * mt + li;
+        load_kfrag<D>(p.ws + (size_t)(m < p.M ? m : 0) * D, m < p.M, kq, wsf[mt]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int mr = 16 * mt + 4 * kq + r;
+            bst[mt][r] = mr < p.M ? p.bs[mr] : 0.f;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int d = 16 * dt + li;
+                of[mt][r][dt] = (mr < p.M && d < D) ? ob[(size_t)mr * D + d] : 0.f;
+            }
+        }
+    }
+    const int p_begin = chunk * p.ppc;
+    const int p_end = min(p.N, p_begin + p.ppc);
+    const size_t row0 = (size_t)b * p.N;
+    for (int g = p_begin + wave * 16; g < p_end; g += 64) {
+        const int pt = g + li;
+        const bool pv = pt < p_end;
+        float xf[KS];
+        load_kfrag<D>(p.xm + (row0 + (pv ? pt : p_begin)) * p.ldx + hh * D, pv, kq, xf);
+        f32x4 w[MT];
+        float mx = NEG_BIG;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            w[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) w[mt] = mfma16(wsf[mt][ks], xf[ks], w[mt]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float z = (w[mt][r] + bst[mt][r]) * inv_tau;
+                if (16 * mt + 4 * kq + r >= p.M) z = NEG_BIG;
+                w[mt][r] = z;
+                mx = fmaxf(mx, z);
+            }
+        }
+        mx = kq_max(mx);
+        float sm = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = expf(w[mt][r] - mx);
+                w[mt][r] = e;
+                sm += e;
+            }
+        sm = kq_sum(sm);
+        const float inv = 1.0f / sm;
+        f32x4 yacc[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) yacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float wv = w[mt][r] * inv;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) yacc[dt] = mfma16(of[mt][r][dt], wv, yacc[dt]);
+            }
+        if (pv) {
+            float* yr = p.y + (row0 + pt) * p.ldy + hh * D;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int d = 16 * dt + 4 * kq;
+                if (d < D) *reinterpret_cast<float4*>(yr + d) = make_float4(yacc[dt][0], yacc[dt][1], yacc[dt][2], yacc[dt][3]);
+            }
+        }
+    }
+}
+
+struct SliceBwdParams {
+    const float* xm; long long ldx;     // x_mid
+    const float* fm; long long ldf;     // fx_mid
+    const float* dy; long long lddy;    // gradient w.r.t. de-sliced y
+    const float* ws; const float* bs; const float* temperature;
+    const float* o; const float* ds; const float* dn;   // [B,heads,M,D] x2, [B,heads,M]
+    float* dxm; long long lddx;         // outputs
+    float* dfm; long long lddf;
+    float* part;                        // per block: [M*D (dWs) | M (dbs) | 1 (dtau)]
+    int B, N, heads, M, nchunk, ppc;
+};
+
+// Backward phase C (per point): recompute W, then
+//   dW = dY.O^T + F.dS^T + dn ; dL = W*(dW - rowsum(dW*W)) ; dF = W.dS ; dX = dL.Ws/tau
+//   dWs += (dL/tau)^T.X ; dbs += sum dL/tau ; dtau -= sum(dL*L)/tau
+template <int D, int MT>
+__global__ __launch_bounds__(256) void slice_bwd_kernel(const SliceBwdParams p) {
+    constexpr int KS = SCfg<D>::KS, DT = SCfg<D>::DT, VEC = SCfg<D>::VEC, NV = SCfg<D>::NV;
+    constexpr int MP = 16 * MT, DP = 16 * DT, P = DP + 4;   // LDS row pitch (floats), 16-B aligned
+    constexpr int TP = MP + 4;                              // pitch of the per-wave dL transpose tile
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const WsL = smem;                 // [MP][P]
+    float* const OL = WsL + MP * P;          // [MP][P]
+    float* const dSL = OL + MP * P;          // [MP][P]
+    float* const bsL = dSL + MP * P;         // [MP]
+    float* const dnL = bsL + MP;             // [MP]
+    float* const TL = dnL + MP;              // [4 waves][16][TP]
+    float* const red = smem;                 // [MP*DP + MP + 4] cross-wave reduction, aliases the
+                                             // fragment matrices (dead after the point loop)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
+    const int chunk = blockIdx.x % p.nchunk;
+    const int hh = (blockIdx.x / p.nchunk) % p.heads;
+    const int b = blockIdx.x / (p.nchunk * p.heads);
+    const float inv_tau = 1.0f / clamp_tau(p.temperature[hh]);
+    const size_t bh = (size_t)(b * p.heads + hh);
+
+    for (int i = tid; i < MP * P; i += 256) {
+        const int m = i / P, d = i % P;
+        const bool ok = m < p.M && d < D;
+        WsL[i] = ok ? p.ws[(size_t)m * D + d] : 0.f;
+        OL[i] = ok ? p.o[(bh * p.M + m) * D + d] : 0.f;
+        dSL[i] = ok ? p.ds[(bh * p.M + m) * D + d] : 0.f;
+    }
+    for (int i = tid; i < MP; i += 256) {
+        bsL[i] = i < p.M ? p.bs[i] : 0.f;
+        dnL[i] = i < p.M ? p.dn[bh * p.M + i] : 0.f;
+    }
+    __syncthreads();
+
+    f32x4 wsacc[MT][DT];
+    float dbacc[MT][4];
+    float dtacc = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            dbacc[mt][r] = 0.f;
+        }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) wsacc[mt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    float* const myT = TL + wave * 16 * TP;
+    const int p_begin = chunk * p.ppc;
+    const int p_end = min(p.N, p_begin + p.ppc);
+    const size_t row0 = (size_t)b * p.N;
+    for (int g = p_begin + wave * 16; g < p_end; g += 64) {
+        const int pt = g + li;
+        const bool pv = pt < p_end;
+        const size_t prow = row0 + (pv ? pt : p_begin);
+        float xf[KS], ff[KS], gf[KS];
+        load_kfrag<D>(p.xm + prow * p.ldx + hh * D, pv, kq, xf);
+        load_kfrag<D>(p.fm + prow * p.ldf + hh * D, pv, kq, ff);
+        load_kfrag<D>(p.dy + prow * p.lddy + hh * D, pv, kq, gf);
+
+        // logits^T and dW^T (rows m = 16mt+4kq+r, cols pt = li)
+        f32x4 w[MT], dw[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            w[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            dw[mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const float* wrow = WsL + (16 * mt + li) * P;
+            const float* orow = OL + (16 * mt + li) * P;
+            const float* srow = dSL + (16 * mt + li) * P;
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                float wa[VEC], oa[VEC], sa[VEC];
+                if constexpr (VEC == 4) {
+                    const float4 q0 = *reinterpret_cast<const float4*>(wrow + 16 * v + 4 * kq);
+                    const float4 q1 = *reinterpret_cast<const float4*>(orow + 16 * v + 4 * kq);
+                    const float4 q2 = *reinterpret_cast<const float4*>(srow + 16 * v + 4 * kq);
+                    wa[0] = q0.x; wa[1] = q0.y; wa[2] = q0.z; wa[3] = q0.w;
+                    oa[0] = q1.x; oa[1] = q1.y; oa[2] = q1.z; oa[3] = q1.w;
+                    sa[0] = q2.x; sa[1] = q2.y; sa[2] = q2.z; sa[3] = q2.w;
+                } else {
+                    const float2 q0 = *reinterpret_cast<const float2*>(wrow + 8 * v + 2 * kq);
+                    const float2 q1 = *reinterpret_cast<const float2*>(orow + 8 * v + 2 * kq);
+                    const float2 q2 = *reinterpret_cast<const float2*>(srow + 8 * v + 2 * kq);
+                    wa[0] = q0.x; wa[1] = q0.y; oa[0] = q1.x; oa[1] = q1.y; sa[0] = q2.x; sa[1] = q2.y;
+                }
+#pragma unroll
+                for (int t = 0; t < VEC; ++t) {
+                    w[mt] = mfma16(wa[t], xf[VEC * v + t], w[mt]);
+                    dw[mt] = mfma16(oa[t], gf[VEC * v + t], dw[mt]);
+                    dw[mt] = mfma16(sa[t], ff[VEC * v + t], dw[mt]);
+                }
+            }
+        }
+        // softmax over m (in-lane + across kq groups); keep scaled logits z for dtau
+        f32x4 z[MT];
+        float mx = NEG_BIG;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = 16 * mt + 4 * kq + r;
+                float zz = (w[mt][r] + bsL[m]) * inv_tau;
+                if (m >= p.M) zz = NEG_BIG;
+                z[mt][r] = zz;
+                mx = fmaxf(mx, zz);
+            }
+        mx = kq_max(mx);
+        float sm = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = expf(z[mt][r] - mx);
+                w[mt][r] = e;
+                sm += e;
+            }
+        sm = kq_sum(sm);
+        const float inv = pv ? 1.0f / sm : 0.f;
+        float rd = 0.f;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = 16 * mt + 4 * kq + r;
+                w[mt][r] *= inv;
+                dw[mt][r] += dnL[m];
+                rd += dw[mt][r] * w[mt][r];
+            }
+        rd = kq_sum(rd);
+        // dL (stored in dw), dbs / dtau accumulation
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float dl = w[mt][r] * (dw[mt][r] - rd);
+                dw[mt][r] = dl;
+                dbacc[mt][r] += dl;
+                if (16 * mt + 4 * kq + r < p.M) dtacc += dl * z[mt][r];
+            }
+        // dF^T = dS^T . W^T ; dX^T = Ws^T . dL^T / tau      (rows d = 16dt+4kq+r', cols pt)
+        f32x4 facc[DT], xacc[DT];
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            facc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            xacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int mrow = (16 * mt + 4 * kq + r) * P;
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    facc[dt] = mfma16(dSL[mrow + 16 * dt + li], w[mt][r], facc[dt]);
+                    xacc[dt] = mfma16(WsL[mrow + 16 * dt + li], dw[mt][r], xacc[dt]);
+                }
+            }
+        if (pv) {
+            float* fr = p.dfm + (row0 + pt) * p.lddf + hh * D;
+            float* xr = p.dxm + (row0 + pt) * p.lddx + hh * D;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int d = 16 * dt + 4 * kq;
+                if (d < D) {
+                    *reinterpret_cast<float4*>(fr + d) = make_float4(facc[dt][0], facc[dt][1], facc[dt][2], facc[dt][3]);
+                    *reinterpret_cast<float4*>(xr + d) = make_float4(xacc[dt][0] * inv_tau, xacc[dt][1] * inv_tau,
+                                                                     xacc[dt][2] * inv_tau, xacc[dt][3] * inv_tau);
+                }
+            }
+        }
+        // dWs += dL^T . X : transpose the 16 x M tile of dL through wave-private LDS so that the
+        // slice index lands on the lane (A operand i = m, k = point)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            *reinterpret_cast<float4*>(myT + li * TP + 16 * mt + 4 * kq) = make_float4(dw[mt][0], dw[mt][1], dw[mt][2], dw[mt][3]);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int pr = g + 4 * kq + r;
+            float xv[DT];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int d = 16 * dt + li;
+                xv[dt] = (pr < p_end && d < D) ? p.xm[(row0 + pr) * p.ldx + hh * D + d] : 0.f;
+            }
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const float a = myT[(4 * kq + r) * TP + 16 * mt + li];
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) wsacc[mt][dt] = mfma16(a, xv[dt], wsacc[mt][dt]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    // block partials: dWs [M][D], dbs [M], dtau — waves add in fixed order
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dbacc[mt][r] = row16_sum(dbacc[mt][r]);
+    dtacc = wave_sum(dtacc);
+    float* const rW = red;
+    float* const rB = red + MP * DP;
+    float* const rT = rB + MP;
+    __syncthreads();
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wave == wv) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = 16 * mt + 4 * kq + r;
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) {
+                        const int idx = m * DP + 16 * dt + li;
+                        rW[idx] = (wv == 0 ? 0.f : rW[idx]) + wsacc[mt][dt][r];
+                    }
+                    if (li == 0) rB[m] = (wv == 0 ? 0.f : rB[m]) + dbacc[mt][r];
+                }
+            if (lane == 0) rT[0] = (wv == 0 ? 0.f : rT[0]) + dtacc;
+        }
+        __syncthreads();
+    }
+    float* po = p.part + (size_t)blockIdx.x * (p.M * D + p.M + 1);
+    for (int i = tid; i < p.M * D; i += 256) po[i] = rW[(i / D) * DP + (i % D)] * inv_tau;
+    for (int i = tid; i < p.M; i += 256) po[p.M * D + i] = rB[i] * inv_tau;
+    if (tid == 0) po[p.M * D + p.M] = -rT[0] * inv_tau;
+}
+
+// dtemperature[h] = mask(0.1 <= t <= 5) * sum over (b, chunk) of the per-block dtau partials
+__global__ void dtau_finalize_kernel(const float* __restrict__ part, const float* __restrict__ temperature,
+                                     float* __restrict__ dtemp, int B, int heads, int nchunk, int stride, int off) {
+    const int hh = blockIdx.x * blockDim.x + threadIdx.x;
+    if (hh >= heads) return;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b)
+        for (int c = 0; c < nchunk; ++c) s += part[(size_t)((b * heads + hh) * nchunk + c) * stride + off];
+    const float t = temperature[hh];
+    dtemp[hh] = (t >= 0.1f && t <= 5.0f) ? s : 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------
+// dispatch over the compile-time (D, MT) grid
+template <int D, int MT>
+static void launch_scatter_t(const SliceParams& p, int grid, hipStream_t st) {
+    hipLaunchKernelGGL((slice_scatter_kernel<D, MT>), dim3(grid), dim3(256), 0, st, p);
+}
+template <int D, int MT>
+static void launch_deslice_t(const DesliceParams& p, int grid, hipStream_t st) {
+    hipLaunchKernelGGL((deslice_kernel<D, MT>), dim3(grid), dim3(256), 0, st, p);
+}
+template <int D, int MT>
+static size_t bwd_smem_bytes() {
+    constexpr int DT = SCfg<D>::DT, MP = 16 * MT, DP = 16 * DT, P = DP + 4, TP = MP + 4;
+    static_assert(MP * DP + MP + 4 <= 3 * MP * P, "reduction scratch must fit in the aliased region");
+    return sizeof(float) * (size_t)(3 * MP * P + 2 * MP + 4 * 16 * TP);
+}
+template <int D, int MT>
+static int launch_bwd_t(const SliceBwdParams& p, int grid, hipStream_t st) {
+    const size_t smem = bwd_smem_bytes<D, MT>();
+    if (smem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&slice_bwd_kernel<D, MT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL((slice_bwd_kernel<D, MT>), dim3(grid), dim3(256), smem, st, p);
+    return PA2D_OK;
+}
+
+#define DISPATCH_MT(D_, CALL)                                    \
+    switch (mt) {                                                \
+        case 1: CALL(D_, 1); break;                              \
+        case 2: CALL(D_, 2); break;                              \
+        case 4: CALL(D_, 4); break;                              \
+        case 8: CALL(D_, 8); break;                              \
+        default: return PA2D_ERR_UNSUPPORTED;                    \
+    }
+#define DISPATCH_D(CALL)                                         \
+    switch (D) {                                                 \
+        case 8: DISPATCH_MT(8, CALL) break;                      \
+        case 16: DISPATCH_MT(16, CALL) break;                    \
+        case 32: DISPATCH_MT(32, CALL) break;                    \
+        case 64: DISPATCH_MT(64, CALL) break;                    \
+        default: return PA2D_ERR_UNSUPPORTED;                    \
+    }
+
+static int mt_for(int M) {
+    if (M <= 16) return 1;
+    if (M <= 32) return 2;
+    if (M <= 64) return 4;
+    if (M <= 128) return 8;
+    return 0;
+}
+
+extern "C" {
+
+// number of point chunks per (batch, head) and points per chunk used by every slice-stage kernel
+int pa2d_slice_nchunk(int B, int N, int heads) {
+    const int bh = B * heads;
+    int nchunk = ceil_div(1024, bh);
+    const int maxc = ceil_div(N, 64);
+    if (nchunk > maxc) nchunk = maxc;
+    if (nchunk < 1) nchunk = 1;
+    int ppc = ceil_div(ceil_div(N, nchunk), 16) * 16;
+    return ceil_div(N, ppc);
+}
+static int ppc_for(int N, int nchunk) { return ceil_div(ceil_div(N, nchunk), 16) * 16; }
+
+// spart [B,heads,nchunk,M,D], npart [B,heads,nchunk,M] (NULL to skip the norm)
+int pa2d_slice_scatter(const float* xm, long long ldx, const float* v, long long ldv, const float* ws,
+                       const float* bs, const float* temperature, float* spart, float* npart, int B, int N,
+                       int heads, int D, int M, hipStream_t st) {
+    const int mt = mt_for(M);
+    if ((ldx & 3) || (D & 7)) return PA2D_ERR_ARG;
+    SliceParams p;
+    p.xm = xm; p.ldx = ldx; p.v = v; p.ldv = ldv; p.ws = ws; p.bs = bs; p.temperature = temperature;
+    p.spart = spart; p.npart = npart; p.B = B; p.N = N; p.heads = heads; p.M = M;
+    p.nchunk = pa2d_slice_nchunk(B, N, heads);
+    p.ppc = ppc_for(N, p.nchunk);
+    const int grid = B * heads * p.nchunk;
+#define CALL_SC(D_, MT_) launch_scatter_t<D_, MT_>(p, grid, st)
+    DISPATCH_D(CALL_SC)
+    PA2D_CHECK_LAUNCH();
+    return PA2D_OK;
+}
+
+int pa2d_deslice_fwd(const float* xm, long long ldx, const float* o, const float* ws, const float* bs,
+                     const float* temperature, float* y, long long ldy, int B, int N, int heads, int D, int M,
+                     hipStream_t st) {
+    const int mt = mt_for(M);
+    if ((ldx & 3) || (ldy & 3) || (D & 7)) return PA2D_ERR_ARG;
+    DesliceParams p;
+    p.xm = xm; p.ldx = ldx; p.o = o; p.ws = ws; p.bs = bs; p.temperature = temperature; p.y = y; p.ldy = ldy;
+    p.B = B; p.N = N; p.heads = heads; p.M = M;
+    p.nchunk = pa2d_slice_nchunk(B, N, heads);
+    p.ppc = ppc_for(N, p.nchunk);
+    const int grid = B * heads * p.nchunk;
+#define CALL_DS(D_, MT_) launch_deslice_t<D_, MT_>(p, grid, st)
+    DISPATCH_D(CALL_DS)
+    PA2D_CHECK_LAUNCH();
+    return PA2D_OK;
+}
+
+size_t pa2d_slice_bwd_workspace(int B, int N, int heads, int D, int M) {
+    const int nchunk = pa2d_slice_nchunk(B, N, heads);
+    return sizeof(float) * ((size_t)B * heads * nchunk + 1) * ((size_t)M * D + M + 1);
+}
+
+// Backward phase C.  dws [M,D], dbs [M], dtemperature [heads] are fully reduced on return.
+int pa2d_slice_bwd_points(const float* xm, long long ldx, const float* fm, long long ldf, const float* dy,
+                          long long lddy, const float* ws, const float* bs, const float* temperature,
+                          const float* o, const float* ds, const float* dn, float* dxm, long long lddx, float* dfm,
+                          long long lddf, float* dws, float* dbs, float* dtemperature, void* ws_buf, size_t ws_bytes,
+                          int B, int N, int heads, int D, int M, hipStream_t st) {
+    const int mt = mt_for(M);
+    if ((ldx & 3) || (ldf & 3) || (lddy & 3) || (lddx & 3) || (lddf & 3) || (D & 7)) return PA2D_ERR_ARG;
+    if (ws_bytes < pa2d_slice_bwd_workspace(B, N, heads, D, M)) return PA2D_ERR_WORKSPACE;
+    SliceBwdParams p;
+    p.xm = xm; p.ldx = ldx; p.fm = fm; p.ldf = ldf; p.dy = dy; p.lddy = lddy; p.ws = ws; p.bs = bs;
+    p.temperature = temperature; p.o = o; p.ds = ds; p.dn = dn; p.dxm = dxm; p.lddx = lddx; p.dfm = dfm;
+    p.lddf = lddf; p.part = (float*)ws_buf; p.B = B; p.N = N; p.heads = heads; p.M = M;
+    p.nchunk = pa2d_slice_nchunk(B, N, heads);
+    p.ppc = ppc_for(N, p.nchunk);
+    const int grid = B * heads * p.nchunk;
+    int rc = PA2D_OK;
+#define CALL_BW(D_, MT_) rc = launch_bwd_t<D_, MT_>(p, grid, st)
+    DISPATCH_D(CALL_BW)
+    if (rc) return rc;
+    PA2D_CHECK_LAUNCH();
+    // sum the per-block records [dWs | dbs | dtau] into one record appended behind them
+    const int stride = M * D + M + 1;
+    float* tail = p.part + (size_t)grid * stride;
+    rc = pa2d_launch_reduce(p.part, grid, stride, tail, st);
+    if (rc) return rc;
+    hipError_t e = hipMemcpyAsync(dws, tail, sizeof(float) * M * D, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return (int)e;
+    e = hipMemcpyAsync(dbs, tail + M * D, sizeof(float) * M, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(dtau_finalize_kernel, dim3(ceil_div(heads, 64)), dim3(64), 0, st, p.part, temperature,
+                       dtemperature, B, heads, p.nchunk, stride, M * D + M);
+    PA2D_CHECK_LAUNCH();
+    return PA2D_OK;
+}
+
+}  // extern "C"

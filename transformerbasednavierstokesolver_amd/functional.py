@@ -1,0 +1,186 @@
+"""Forward/backward compositions of the libpa2d stages and their autograd wrappers.
+
+One autograd node per stage group (LayerNorm, Physics-Attention incl. to_out + residual, MLP incl.
+residual, head) instead of the ~120 nodes per layer the reference builds; the slice
+weights [B,h,N,M] are never saved — backward recomputes them from x_mid inside the kernels.
+"""
+from __future__ import annotations
+
+import torch
+from torch.autograd import Function
+
+from . import ops
+
+
+# ------------------------------------------------------------------------------ Physics-Attention
+def attn_forward(xn, P, res, H, W, heads):
+    """xn [B,N,C] (already layer-normed).  P: dict of parameter tensors.  Returns (out, saved)."""
+    B, N, C = xn.shape
+    D = C // heads
+    M = P["ws"].shape[0]
+    temp = P["temperature"].reshape(heads).contiguous()
+    xf = ops.conv3x3x2_fwd(xn, P["wx"], P["bx"], P["wf"], P["bf"], H, W)                       # [B,N,2C]
+    spart, npart = ops.slice_scatter(xf, 2 * C, 0, xf, 2 * C, C, P["ws"], P["bs"], temp, B, N, heads, D, M)
+    s, nrm, o = ops.token_attn_fwd(spart, npart, P["wq"], P["wk"], P["wv"])
+    y = ops.deslice_fwd(xf, 2 * C, 0, o, P["ws"], P["bs"], temp, B, N, heads, D, M)          # [B,N,C]
+    out, _ = ops.linear_fwd(y.view(B * N, C), P["wo"], P["bo"],
+                            res=None if res is None else res.reshape(B * N, C))
+    return out.view(B, N, C), (xn, xf, s, nrm, o, y, temp)
+
+
+def attn_backward(saved, P, dout, H, W, heads, need_dx=True):
+    xn, xf, s, nrm, o, y, temp = saved
+    B, N, C = xn.shape
+    D = C // heads
+    M = P["ws"].shape[0]
+    d2 = dout.reshape(B * N, C)
+    dy = ops.linear_bwd_data(d2, P["wo"])                                                     # [B*N,C]
+    dwo, dbo = ops.linear_bwd_weight(d2, y.view(B * N, C))
+    dopart, _ = ops.slice_scatter(xf, 2 * C, 0, dy, C, 0, P["ws"], P["bs"], temp, B, N, heads, D, M,
+                                  want_norm=False)
+    ds, dn, dwq, dwk, dwv = ops.token_attn_bwd(s, nrm, P["wq"], P["wk"], P["wv"], dopart)
+    dxf, dws, dbs, dtemp = ops.slice_bwd_points(xf, dy, P["ws"], P["bs"], temp, o, ds, dn, B, N, heads, D, M)
+    dxn, dwx, dbx, dwf, dbf = ops.conv3x3x2_bwd(dxf, xn, P["wx"], P["wf"], H, W, need_dx=need_dx)
+    grads = dict(temperature=dtemp.view(1, heads, 1, 1), wx=dwx, bx=dbx, wf=dwf, bf=dbf, ws=dws, bs=dbs,
+                 wq=dwq, wk=dwk, wv=dwv, wo=dwo, bo=dbo)
+    return dxn, grads
+
+
+ATTN_KEYS = ("temperature", "wx", "bx", "wf", "bf", "ws", "bs", "wq", "wk", "wv", "wo", "bo")
+
+
+class PhysicsAttentionFn(Function):
+    """out = to_out(deslice(attn(slice(conv(xn))))) (+ res)."""
+
+    @staticmethod
+    def forward(ctx, xn, res, H, W, heads, *params):
+        P = dict(zip(ATTN_KEYS, (p.detach().contiguous() for p in params)))
+        out, saved = attn_forward(xn.detach().contiguous(), P, None if res is None else res.detach().contiguous(),
+                                  H, W, heads)
+        ctx.P, ctx.saved, ctx.geom = P, saved, (H, W, heads)
+        ctx.has_res = res is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        H, W, heads = ctx.geom
+        dout = dout.contiguous()
+        dxn, g = attn_backward(ctx.saved, ctx.P, dout, H, W, heads, need_dx=ctx.needs_input_grad[0])
+        return (dxn, dout if ctx.has_res else None, None, None, None) + tuple(g[k] for k in ATTN_KEYS)
+
+
+# ------------------------------------------------------------------------------ MLP (Linear-act-Linear)
+def mlp_forward(x2d, w1, b1, w2, b2, act, res2d):
+    hact, hpre = ops.linear_fwd(x2d, w1, b1, act=act, want_pre=True)
+    out, _ = ops.linear_fwd(hact, w2, b2, res=res2d)
+    return out, (x2d, hpre, hact)
+
+
+def mlp_backward(saved, w1, w2, act, dout2d, need_dx=True):
+    x2d, hpre, hact = saved
+    dhpre = ops.linear_bwd_data(dout2d, w2, pre=hpre, act=act)
+    dw2, db2 = ops.linear_bwd_weight(dout2d, hact)
+    dw1, db1 = ops.linear_bwd_weight(dhpre, x2d)
+    dx = ops.linear_bwd_data(dhpre, w1) if need_dx else None
+    return dx, dw1, db1, dw2, db2
+
+
+class MLPFn(Function):
+    """linear_post(act(linear_pre(x))) (+ res) for the n_layers=0 MLP of the reference."""
+
+    @staticmethod
+    def forward(ctx, x, res, act, w1, b1, w2, b2):
+        shp = x.shape
+        x2d = x.detach().reshape(-1, shp[-1]).contiguous()
+        w1, b1, w2, b2 = (t.detach().contiguous() for t in (w1, b1, w2, b2))
+        res2d = None if res is None else res.detach().reshape(-1, w2.shape[0]).contiguous()
+        out, saved = mlp_forward(x2d, w1, b1, w2, b2, act, res2d)
+        ctx.saved, ctx.w, ctx.act, ctx.shp, ctx.has_res = saved, (w1, w2), act, shp, res is not None
+        return out.view(*shp[:-1], w2.shape[0])
+
+    @staticmethod
+    def backward(ctx, dout):
+        w1, w2 = ctx.w
+        d2 = dout.reshape(-1, w2.shape[0]).contiguous()
+        dx, dw1, db1, dw2, db2 = mlp_backward(ctx.saved, w1, w2, ctx.act, d2, need_dx=ctx.needs_input_grad[0])
+        return (None if dx is None else dx.view(ctx.shp), dout if ctx.has_res else None, None, dw1, db1, dw2, db2)
+
+
+# ------------------------------------------------------------------------------ LayerNorm / head
+class LayerNormFn(Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta):
+        shp = x.shape
+        x2d = x.detach().reshape(-1, shp[-1]).contiguous()
+        gamma, beta = gamma.detach().contiguous(), beta.detach().contiguous()
+        y, mean, rstd = ops.layernorm_fwd(x2d, gamma, beta)
+        ctx.saved, ctx.shp = (x2d, mean, rstd, gamma), shp
+        return y.view(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2d, mean, rstd, gamma = ctx.saved
+        dx, dg, db = ops.layernorm_bwd(dy.reshape(x2d.shape).contiguous(), x2d, mean, rstd, gamma)
+        return dx.view(ctx.shp), dg, db
+
+
+class HeadFn(Function):
+    """mlp2: Linear(C, out_dim <= 8)."""
+
+    @staticmethod
+    def forward(ctx, xn, w, b):
+        shp = xn.shape
+        x2d = xn.detach().reshape(-1, shp[-1]).contiguous()
+        w, b = w.detach().contiguous(), b.detach().contiguous()
+        ctx.saved, ctx.shp = (x2d, w), shp
+        return ops.head_fwd(x2d, w, b).view(*shp[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2d, w = ctx.saved
+        dxn, dw, db = ops.head_bwd(dy.reshape(-1, w.shape[0]).contiguous(), x2d, w)
+        return dxn.view(ctx.shp), dw, db
+
+
+class LinearFn(Function):
+    """y = act(x . w^T + b): generic dense layer (MLP hidden layers when n_layers > 0, wide heads)."""
+
+    @staticmethod
+    def forward(ctx, x, act, w, b):
+        shp = x.shape
+        x2d = x.detach().reshape(-1, shp[-1]).contiguous()
+        w = w.detach().contiguous()
+        b = None if b is None else b.detach().contiguous()
+        y, pre = ops.linear_fwd(x2d, w, b, act=act, want_pre=act is not None)
+        ctx.saved, ctx.act, ctx.shp, ctx.has_b = (x2d, w, pre), act, shp, b is not None
+        return y.view(*shp[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2d, w, pre = ctx.saved
+        d2 = dy.reshape(-1, w.shape[0]).contiguous()
+        if ctx.act is not None:
+            d2 = ops.act_bwd(d2, pre, ctx.act)
+        dw, db = ops.linear_bwd_weight(d2, x2d, want_bias=ctx.has_b)
+        dx = ops.linear_bwd_data(d2, w).view(ctx.shp) if ctx.needs_input_grad[0] else None
+        return dx, None, dw, db
+
+
+def linear(x, w, b, act):
+    return LinearFn.apply(x, act, w, b)
+
+
+def layer_norm(x, gamma, beta):
+    return LayerNormFn.apply(x, gamma, beta)
+
+
+def physics_attention(xn, res, H, W, heads, params):
+    return PhysicsAttentionFn.apply(xn, res, H, W, heads, *params)
+
+
+def mlp(x, res, act, w1, b1, w2, b2):
+    return MLPFn.apply(x, res, act, w1, b1, w2, b2)
+
+
+def head(xn, w, b):
+    return HeadFn.apply(xn, w, b)
