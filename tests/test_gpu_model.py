@@ -1,0 +1,179 @@
+"""End-to-end parity of the HIP path (Model / Attn / SOL / harness) against the golden vectors the
+REFERENCE produced in the build container (tests/golden/G*.npz, made by oracle/make_golden.py).
+Tolerances follow SURVEY.md §8c: fp32 forward rel-L2 <= 1e-5 per call, <= 2e-4 after 20 rollout
+steps; gradients <= 1e-4 (<= 2e-3 for to_q/to_k)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _sample(t, n=257):
+    f = torch.as_tensor(t).detach().double().cpu().numpy().ravel()
+    stride = max(1, f.size // n)
+    return f[::stride][:n]
+
+
+def _grad_tol(key):
+    return 2e-3 if ("to_q" in key or "to_k" in key) else 1e-4
+
+
+def test_g1_tiny_model_forward_and_all_grads():
+    from transformerbasednavierstokesolver_amd import synth, harness
+    from transformerbasednavierstokesolver_amd.utils.testloss import TestLoss
+    g = np.load(os.path.join(GOLDEN, "G1_tiny.npz"))
+    sd = {k[3:]: g[k] for k in g.files if k.startswith("sd.")}
+    m = harness.build_model(synth.TINY_CONFIG, sd, DEV)
+    x, fx, y = (torch.from_numpy(g[k]).to(DEV) for k in ("x", "fx", "y"))
+    pred = m(x, fx=fx)
+    assert rel_l2(pred, g["pred.f64"]) < 1e-5
+    loss = TestLoss(size_average=False)(pred.reshape(2, -1), y.reshape(2, -1))
+    assert abs(loss.item() - float(g["loss.f64"])) < 1e-5 * abs(float(g["loss.f64"]))
+    loss.backward()
+    for k, p in m.named_parameters():
+        if k == "placeholder":
+            assert p.grad is None
+            continue
+        e = rel_l2(p.grad, g["grad.f64." + k])
+        assert e < _grad_tol(k), (k, e)
+
+
+def test_g1b_fx_none_and_time_input_branches():
+    from transformerbasednavierstokesolver_amd import synth, harness
+    g = np.load(os.path.join(GOLDEN, "G1b_tiny_branches.npz"))
+    cfg = dict(synth.TINY_CONFIG, fun_dim=0, Time_Input=True, unified_pos=0)
+    m = harness.build_model(cfg, synth.synth_state_dict(cfg, seed=12), DEV)
+    x = torch.from_numpy(g["x"]).to(DEV)
+    T = torch.from_numpy(g["T"]).reshape(-1, 1).to(DEV)
+    with torch.no_grad():
+        pred = m(x, None, T=T)
+    assert rel_l2(pred, g["pred"]) < 2e-5
+
+
+def test_g2_attention_module_ns_shape():
+    from transformerbasednavierstokesolver_amd import synth
+    from transformerbasednavierstokesolver_amd.model.Physics_Attention import Physics_Attention_Structured_Mesh_2D
+    g = np.load(os.path.join(GOLDEN, "G2_attn_ns.npz"))
+    cfg = synth.NS_CONFIG
+    sd_all = synth.synth_state_dict(dict(cfg, n_layers=1), seed=21)
+    pre = "blocks.0.Attn."
+    C, h = cfg["n_hidden"], cfg["n_head"]
+    a = Physics_Attention_Structured_Mesh_2D(C, heads=h, dim_head=C // h, slice_num=cfg["slice_num"], H=64, W=64)
+    a.load_state_dict({k[len(pre):]: torch.from_numpy(v) for k, v in sd_all.items() if k.startswith(pre)}, strict=True)
+    a = a.to(DEV)
+    rng = np.random.default_rng(22)
+    x = torch.from_numpy(rng.standard_normal((1, 4096, C)).astype(np.float32)).to(DEV).requires_grad_(True)
+    gy = torch.from_numpy(rng.standard_normal((1, 4096, C)).astype(np.float32)).to(DEV)
+    y = a(x)
+    y.backward(gy)
+    assert rel_l2(_sample(y), g["y.sample"]) < 1e-5
+    assert abs(float(y.detach().double().norm()) - float(g["y.norm"])) < 1e-5 * float(g["y.norm"])
+    assert rel_l2(_sample(x.grad), g["dx.sample"]) < 1e-4
+    for k, p in a.named_parameters():
+        assert rel_l2(_sample(p.grad, 129), g["grad.sample." + k]) < _grad_tol(k), k
+        assert abs(float(p.grad.double().norm()) - float(g["grad.norm." + k])) < _grad_tol(k) * float(g["grad.norm." + k]), k
+
+
+def test_g3_shipped_checkpoint_rollout_eager_and_graph():
+    """The reference's own trained weights, 20-step prediction-feedback rollout."""
+    from transformerbasednavierstokesolver_amd import synth, harness
+    g = np.load(os.path.join(GOLDEN, "G3_shipped_rollout.npz"))
+    ck = np.load(os.path.join(GOLDEN, "ckpt_ep400_sim100.npz"))
+    m = harness.build_model(synth.NS_SMALL_CONFIG, {k: ck[k] for k in ck.files}, DEV).eval()
+    pos, a, _ = synth.ns_batch(2, seed=31)
+    x, fx = torch.from_numpy(pos).to(DEV), torch.from_numpy(a).to(DEV)
+    fr = harness.rollout(m, x, fx, 20)
+    for t, tol in ((0, 1e-5), (4, 1e-4), (9, 2e-4), (19, 2e-4)):
+        # SURVEY §8c acceptance: stated tolerance OR "error vs the fp64 reference <= 4x the fp32
+        # reference's own error" — on these out-of-distribution synthetic fields the reference's own
+        # fp32 rollout is 4.0e-4 away from its fp64 rollout at frame 20 (both stored in the fixture).
+        ref32 = rel_l2(g[f"frame{t + 1}.f32.sample"], g[f"frame{t + 1}.f64.sample"])
+        tol = max(tol, 4 * ref32)
+        assert rel_l2(_sample(fr[..., t]), g[f"frame{t + 1}.f64.sample"]) < tol, t
+        assert abs(float(fr[..., t].double().norm()) - float(g[f"frame{t + 1}.f64.norm"])) < tol * float(g[f"frame{t + 1}.f64.norm"])
+    gr = harness.GraphedRollout(m, x, fx)
+    fr2 = gr.run(fx, 20)
+    assert torch.equal(fr, fr2), "hipGraph replay must be bit-identical to the eager loop"
+
+
+def test_g4_training_iteration_and_optimizer_step():
+    from transformerbasednavierstokesolver_amd import synth, harness
+    g = np.load(os.path.join(GOLDEN, "G4_train_iteration.npz"))
+    cfg = synth.NS_SMALL_CONFIG
+    m = harness.build_model(cfg, synth.synth_state_dict(cfg, seed=41), DEV).train()
+    pos, a, u = synth.ns_batch(2, seed=42)
+    x, fx, yy = (torch.from_numpy(t).to(DEV) for t in (pos, a, u))
+    opt = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-5)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-3, epochs=5, steps_per_epoch=7)
+    loss, full, pred = harness.train_iteration(m, x, fx, yy)
+    assert abs(loss.item() - float(g["loss"])) < 1e-5 * float(g["loss"])
+    assert abs(full.item() - float(g["full"])) < 1e-5 * float(g["full"])
+    assert rel_l2(_sample(pred), g["pred.sample"]) < 1e-5
+    opt.zero_grad()
+    loss.backward()
+    for k, p in m.named_parameters():
+        if k == "placeholder":
+            assert p.grad is None
+            continue
+        assert rel_l2(_sample(p.grad, 65), g["grad.sample." + k]) < _grad_tol(k), k
+        assert abs(float(p.grad.double().norm()) - float(g["grad.norm." + k])) < _grad_tol(k) * float(g["grad.norm." + k]), k
+    opt.step()
+    sched.step()
+    assert abs(sched.get_last_lr()[0] - float(g["lr1"])) < 1e-12
+    for k, p in m.named_parameters():
+        assert abs(float(p.detach().double().norm()) - float(g["param1.norm." + k])) < 1e-5 * float(g["param1.norm." + k]) + 1e-12, k
+
+
+def test_g5_full_ns_config_forward_backward():
+    """BASELINE configs[1] architecture: 8 layers, C=256, 8 heads, M=64, 64x64."""
+    from transformerbasednavierstokesolver_amd import synth, harness
+    from transformerbasednavierstokesolver_amd.utils.testloss import TestLoss
+    g = np.load(os.path.join(GOLDEN, "G5_full_ns.npz"))
+    cfg = synth.NS_CONFIG
+    m = harness.build_model(cfg, synth.synth_state_dict(cfg, seed=51), DEV)
+    pos, a, u = synth.ns_batch(1, seed=52)
+    x, fx, y = (torch.from_numpy(t).to(DEV) for t in (pos, a, u[..., :1]))
+    pred = m(x, fx=fx)
+    assert rel_l2(pred.reshape(-1), g["pred"]) < 1e-5
+    loss = TestLoss(size_average=False)(pred.reshape(1, -1), y.reshape(1, -1))
+    assert abs(loss.item() - float(g["loss"])) < 1e-5 * float(g["loss"])
+    loss.backward()
+    for k, p in m.named_parameters():
+        if k == "placeholder":
+            continue
+        assert rel_l2(_sample(p.grad, 65), g["grad.sample." + k]) < _grad_tol(k), k
+        assert abs(float(p.grad.double().norm()) - float(g["grad.norm." + k])) < _grad_tol(k) * float(g["grad.norm." + k]), k
+
+
+def test_sol_wrapper_bptt_matches_oracle():
+    """SOL_Transolver (n chained calls, predictions fed back, BPTT through all of them) vs the oracle."""
+    from transformerbasednavierstokesolver_amd import synth
+    from transformerbasednavierstokesolver_amd.model.SOL_Transolver_Structured_Mesh_2D import SOL_Transolver_Structured_Mesh_2D
+    from oracle import transolver_oracle as orc
+    cfg = dict(synth.TINY_CONFIG, out_dim=1, fun_dim=4)
+    sd = synth.synth_state_dict(cfg, seed=61)
+    kw = {k: cfg[k] for k in ("space_dim", "n_layers", "n_hidden", "dropout", "n_head", "Time_Input", "act", "mlp_ratio",
+                              "fun_dim", "out_dim", "slice_num", "ref", "unified_pos", "H", "W")}
+    sol = SOL_Transolver_Structured_Mesh_2D(**kw, step=1, look_ahead=3)
+    sol.transolver_model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    sol = sol.to(DEV)
+    rng = np.random.default_rng(62)
+    N = cfg["H"] * cfg["W"]
+    x = torch.from_numpy(rng.standard_normal((2, N, 2)).astype(np.float32))
+    fx = torch.from_numpy(rng.standard_normal((2, N, 4)).astype(np.float32))
+    u = sol(x.to(DEV), fx.to(DEV))
+    u.square().sum().backward()
+    sdo = orc.to_torch(sd, torch.float64, requires_grad=True)
+    uo = orc.sol_forward(sdo, x.double(), fx.double(), cfg, 3)
+    uo.square().sum().backward()
+    assert rel_l2(u, uo) < 1e-5
+    for k, p in sol.transolver_model.named_parameters():
+        if k == "placeholder":
+            continue
+        assert rel_l2(p.grad, sdo[k].grad) < _grad_tol(k), k
