@@ -62,15 +62,19 @@ int pa2d_gemm_bwd_weight(const float* dy, long long lddy, const float* x, long l
 /* ---- in_project_x / in_project_fx: two Conv2d(C, C, 3, 1, 1) on the same input,
  * Physics_Attention.py:74-75,91-97, as ONE implicit GEMM on the NHWC ([B,N,C]) tensor.
  * out[B*H*W, 2C] = [x_mid | fx_mid] (heads are channel groups h*D..h*D+D-1 of each half).
- * Weights in the checkpoint layout [C_out, C_in, 3, 3].  Requires C % 16 == 0. */
+ * Weights in the checkpoint layout [C_out, C_in, 3, 3].  Requires C % 16 == 0.
+ * ev_start / ev_stop: optional hipEvent_t (NULL = none) recorded on `stream` immediately around the
+ * implicit-GEMM launch (forward: the [B*N,9C]x[9C,2C] product; backward: the data-gradient product),
+ * so a benchmark can time that kernel alone without a profiler. */
 size_t pa2d_conv3x3x2_workspace(int B, int H, int W, int C);
 int pa2d_conv3x3x2_fwd(const float* xn, const float* wx, const float* bx, const float* wf, const float* bf,
                        float* out, float* bias2_ws /* 2C floats */, void* ws, size_t ws_bytes, int B, int H,
-                       int W, int C, pa2d_stream_t stream);
+                       int W, int C, pa2d_stream_t stream, void* ev_start, void* ev_stop);
 /* dxn may be NULL (input needs no gradient) */
 int pa2d_conv3x3x2_bwd(const float* dout, const float* xn, const float* wx, const float* wf, float* dxn,
                        float* dwx, float* dbx, float* dwf, float* dbf, float* dbias2_ws /* 2C floats */,
-                       void* ws, size_t ws_bytes, int B, int H, int W, int C, pa2d_stream_t stream);
+                       void* ws, size_t ws_bytes, int B, int H, int W, int C, pa2d_stream_t stream,
+                       void* ev_start, void* ev_stop);
 
 /* ---- slice: softmax((x_mid . Ws^T + bs) / clamp(temperature, .1, 5)) and the weighted scatter of
  * N points into M tokens, Physics_Attention.py:98-101.  Emits per-chunk partial sums

@@ -186,11 +186,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KCParams p) {
     }
 }
 
-static int launch_kc(const KCParams& p, bool im2col, hipStream_t st) {
+static int launch_kc(const KCParams& p, bool im2col, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return PA2D_OK;
     if ((p.K & 3) || (p.lda & 3) || (p.ldb & 3)) return PA2D_ERR_ARG;
     if (im2col && ((p.Cin & 15) || p.K != 9 * p.Cin)) return PA2D_ERR_UNSUPPORTED;
     const int tiles_m = ceil_div(p.M, 128);
+    if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return PA2D_ERR_ARG;
     if (p.N > 64) {
         const int tiles_n = ceil_div(p.N, 128);
         const dim3 grid(ceil_div(tiles_m, 8) * 8 * tiles_n);
@@ -203,6 +204,7 @@ static int launch_kc(const KCParams& p, bool im2col, hipStream_t st) {
         else hipLaunchKernelGGL((gemm_kc_kernel<128, 64, 4, 1, false>), grid, dim3(256), 0, st, p);
     }
     PA2D_CHECK_LAUNCH();
+    if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return PA2D_ERR_ARG;
     return PA2D_OK;
 }
 
@@ -529,7 +531,7 @@ size_t pa2d_conv3x3x2_workspace(int B, int H, int W, int C) {
 // GEMM [B*N, 9C] x [9C, 2C].
 int pa2d_conv3x3x2_fwd(const float* xn, const float* wx, const float* bx, const float* wf, const float* bf,
                        float* out, float* bias2_ws /* 2C floats */, void* ws, size_t ws_bytes, int B, int H, int W,
-                       int C, hipStream_t st) {
+                       int C, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (ws_bytes < (size_t)2 * C * 9 * C * sizeof(float)) return PA2D_ERR_WORKSPACE;
     float* pack = (float*)ws;
     int rc = launch_repack(wx, wf, pack, 1, 0, 0, C, C, st);
@@ -541,13 +543,14 @@ int pa2d_conv3x3x2_fwd(const float* xn, const float* wx, const float* bx, const 
     KCParams p = {};
     p.A = xn; p.lda = C; p.B = pack; p.ldb = 9 * C; p.C = out; p.ldc = 2 * C; p.bias = bias2_ws;
     p.M = B * H * W; p.N = 2 * C; p.K = 9 * C; p.H = H; p.W = W; p.Cin = C;
-    return launch_kc(p, true, st);
+    return launch_kc(p, true, st, ev_start, ev_stop);
 }
 
 // dxn[B*N, C] (+= nothing; plain store), dwx/dwf [C,C,3,3], dbx/dbf [C]  from dout[B*N, 2C]
 int pa2d_conv3x3x2_bwd(const float* dout, const float* xn, const float* wx, const float* wf, float* dxn, float* dwx,
                        float* dbx, float* dwf, float* dbf, float* dbias2_ws /* 2C floats */, void* ws,
-                       size_t ws_bytes, int B, int H, int W, int C, hipStream_t st) {
+                       size_t ws_bytes, int B, int H, int W, int C, hipStream_t st, hipEvent_t ev_start,
+                       hipEvent_t ev_stop) {
     if (ws_bytes < pa2d_conv3x3x2_workspace(B, H, W, C)) return PA2D_ERR_WORKSPACE;
     float* pack = (float*)ws;
     float* scratch = pack + (size_t)2 * C * 9 * C;
@@ -559,7 +562,7 @@ int pa2d_conv3x3x2_bwd(const float* dout, const float* xn, const float* wx, cons
         KCParams p = {};
         p.A = dout; p.lda = 2 * C; p.B = pack; p.ldb = 9 * 2 * C; p.C = dxn; p.ldc = C;
         p.M = M; p.N = C; p.K = 9 * 2 * C; p.H = H; p.W = W; p.Cin = 2 * C;
-        rc = launch_kc(p, true, st);
+        rc = launch_kc(p, true, st, ev_start, ev_stop);
         if (rc) return rc;
     }
     const MCPlan pl = plan_mc(2 * C, 9 * C, M);

@@ -15,6 +15,15 @@ ACT_IDS = {None: 0, "none": 0, "gelu": 1, "tanh": 2, "sigmoid": 3, "relu": 4, "s
 LN_EPS = 1e-5
 
 
+# Optional provider of (hipEvent_t start, hipEvent_t stop) handles recorded around the conv
+# implicit-GEMM launches (bench.py installs one to time the dominant kernel live); None = off.
+conv_event_provider = None
+
+
+def _conv_events():
+    return conv_event_provider() if conv_event_provider is not None else (0, 0)
+
+
 def _L():
     return _lib.load()
 
@@ -113,8 +122,9 @@ def conv3x3x2_fwd(xn, wx, bx, wf, bf, H, W):
     bias2 = torch.empty(2 * Cc, dtype=torch.float32, device=xn.device)
     nb = _L().pa2d_conv3x3x2_workspace(B, H, W, Cc)
     ws = _ws(nb, xn)
+    e0, e1 = _conv_events()
     _lib.check(_L().pa2d_conv3x3x2_fwd(_p(xn), _p(wx), _p(bx), _p(wf), _p(bf), _p(out), _p(bias2), ws.data_ptr(), nb,
-                                       B, H, W, Cc, _stream()), "conv3x3x2_fwd")
+                                       B, H, W, Cc, _stream(), e0, e1), "conv3x3x2_fwd")
     return out
 
 
@@ -128,8 +138,9 @@ def conv3x3x2_bwd(dout, xn, wx, wf, H, W, need_dx=True):
     db2 = torch.empty(2 * Cc, dtype=torch.float32, device=xn.device)
     nb = _L().pa2d_conv3x3x2_workspace(B, H, W, Cc)
     ws = _ws(nb, xn)
+    e0, e1 = _conv_events() if need_dx else (0, 0)
     _lib.check(_L().pa2d_conv3x3x2_bwd(_p(dout), _p(xn), _p(wx), _p(wf), _p(dxn), _p(dwx), _p(dbx), _p(dwf), _p(dbf),
-                                       _p(db2), ws.data_ptr(), nb, B, H, W, Cc, _stream()), "conv3x3x2_bwd")
+                                       _p(db2), ws.data_ptr(), nb, B, H, W, Cc, _stream(), e0, e1), "conv3x3x2_bwd")
     return dxn, dwx, dbx, dwf, dbf
 
 
