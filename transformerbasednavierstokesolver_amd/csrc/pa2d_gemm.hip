@@ -38,7 +38,22 @@ struct KCParams {
     int M, N, K;
     int act, epi;
     int H, W, Cin;   // im2col view: A = image [B,H,W,Cin] with pixel pitch lda, K = 9*Cin
+    unsigned a_bytes, b_bytes;   // extents of A and B for the buffer descriptors (filled by launch_kc)
 };
+
+// Raw buffer loads: lanes whose byte offset is >= num_records return 0 from the hardware range
+// check, so masked (padding / out-of-tile) elements need neither branches nor selects and the loads
+// stay asynchronous until the compiler's vmcnt wait in front of the LDS store.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define OOB_OFF 0xFFFFFFFFu
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool IM2COL>
 __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KCParams p) {
@@ -53,25 +68,26 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KCParams p) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_n = (p.N + BN - 1) / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
-    // XCD-aware map: blocks b, b+8, ... share an XCD (round-robin dispatch), so give the tiles_n
-    // column tiles of one row tile (same A panel) to ids congruent mod 8.
-    const int group = blockIdx.x / (8 * tiles_n);
-    const int loc = blockIdx.x - group * 8 * tiles_n;
-    const int tile_m = group * 8 + (loc & 7);
-    const int tile_n = loc >> 3;
-    if (tile_m >= tiles_m) return;
+    // XCD-aware map (speed only): blocks b, b+8, ... share an XCD under round-robin dispatch.  Each
+    // XCD walks a CONTIGUOUS range of row tiles, all column tiles of a row tile back to back, so
+    // co-resident blocks share the A panel (and, for the conv, the halo rows) in that XCD's L2.
+    const int tmx = (tiles_m + 7) / 8;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tile_m = xcd * tmx + slot / tiles_n;
+    const int tile_n = slot % tiles_n;
+    if (tile_m >= tiles_m || slot / tiles_n >= tmx) return;
 
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int lr = tid >> 2, lq = tid & 3;
 
-    const float* a_base[A_IT];
-    bool a_ok[A_IT];
+    const __amdgpu_buffer_rsrc_t ra_rsrc = make_rsrc(p.A, p.a_bytes);
+    const __amdgpu_buffer_rsrc_t rb_rsrc = make_rsrc(p.B, p.b_bytes);
+    unsigned a_off[A_IT], b_off[B_IT];
     int a_y[A_IT], a_x[A_IT];
 #pragma unroll
     for (int s = 0; s < A_IT; ++s) {
         const int gm = tile_m * BM + lr + 64 * s;
-        a_ok[s] = gm < p.M;
-        a_base[s] = p.A + (size_t)(a_ok[s] ? gm : 0) * p.lda;
+        a_off[s] = gm < p.M ? (unsigned)gm * (unsigned)p.lda * 4u + lq * 16u : OOB_OFF;
         if (IM2COL) {
             const int n = gm % (p.H * p.W);
             a_y[s] = n / p.W;
@@ -80,49 +96,13 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KCParams p) {
             a_y[s] = a_x[s] = 0;
         }
     }
-    const float* b_base[B_IT];
-    bool b_ok[B_IT];
 #pragma unroll
     for (int s = 0; s < B_IT; ++s) {
         const int gn = tile_n * BN + lr + 64 * s;
-        b_ok[s] = gn < p.N;
-        b_base[s] = p.B + (size_t)(b_ok[s] ? gn : 0) * p.ldb;
+        b_off[s] = gn < p.N ? (unsigned)gn * (unsigned)p.ldb * 4u + lq * 16u : OOB_OFF;
     }
 
     float4 ra[A_IT], rb[B_IT];
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto load_chunk = [&](int kc) {
-        const int k0 = kc * BK;
-        const int k = k0 + lq * 4;
-        const bool kin = k < p.K;
-        if (IM2COL) {
-            const int tap = k0 / p.Cin;
-            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-            const long long off = (long long)(dy * p.W + dx) * p.lda + (k - tap * p.Cin);
-#pragma unroll
-            for (int s = 0; s < A_IT; ++s) {
-                const bool ok = a_ok[s] && kin && (unsigned)(a_y[s] + dy) < (unsigned)p.H &&
-                                (unsigned)(a_x[s] + dx) < (unsigned)p.W;
-                ra[s] = ok ? *reinterpret_cast<const float4*>(a_base[s] + off) : zero4;
-            }
-        } else {
-#pragma unroll
-            for (int s = 0; s < A_IT; ++s)
-                ra[s] = (a_ok[s] && kin) ? *reinterpret_cast<const float4*>(a_base[s] + k) : zero4;
-        }
-#pragma unroll
-        for (int s = 0; s < B_IT; ++s)
-            rb[s] = (b_ok[s] && kin) ? *reinterpret_cast<const float4*>(b_base[s] + k) : zero4;
-    };
-    auto store_chunk = [&](int buf) {
-#pragma unroll
-        for (int s = 0; s < A_IT; ++s)
-            *reinterpret_cast<float4*>(As + buf * BM * PITCH + (lr + 64 * s) * PITCH + lq * 4) = ra[s];
-#pragma unroll
-        for (int s = 0; s < B_IT; ++s)
-            *reinterpret_cast<float4*>(Bs + buf * BN * PITCH + (lr + 64 * s) * PITCH + lq * 4) = rb[s];
-    };
-
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -132,13 +112,44 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KCParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = (p.K + BK - 1) / BK;
-    load_chunk(0);
-    store_chunk(0);
+    // K order of the implicit-GEMM conv: k = (ci_chunk*9 + tap)*16 + c, i.e. the 9 taps of one
+    // 16-channel chunk are consecutive K-steps: they re-touch the same 64-B segments of the same
+    // image rows (shifted by one pixel), which are then L1/L2 hits instead of fresh misses.
+#define KC_LOAD(kc_)                                                                                   \
+    {                                                                                                  \
+        const int k0_ = (kc_) * BK;                                                                    \
+        const bool kin_ = k0_ + lq * 4 < p.K;                                                          \
+        if (IM2COL) {                                                                                  \
+            const int cic_ = (kc_) / 9, tap_ = (kc_) - cic_ * 9;                                       \
+            const int dy_ = tap_ / 3 - 1, dx_ = tap_ - (tap_ / 3) * 3 - 1;                             \
+            const int sh_ = ((dy_ * p.W + dx_) * (int)p.lda + cic_ * BK) * 4;                          \
+            _Pragma("unroll") for (int s = 0; s < A_IT; ++s) {                                         \
+                const bool ok_ = (unsigned)(a_y[s] + dy_) < (unsigned)p.H &&                           \
+                                 (unsigned)(a_x[s] + dx_) < (unsigned)p.W && a_off[s] != OOB_OFF;      \
+                ra[s] = buf_load4(ra_rsrc, ok_ ? a_off[s] + (unsigned)sh_ : OOB_OFF);                  \
+            }                                                                                          \
+        } else {                                                                                       \
+            _Pragma("unroll") for (int s = 0; s < A_IT; ++s)                                           \
+                ra[s] = buf_load4(ra_rsrc, (kin_ && a_off[s] != OOB_OFF) ? a_off[s] + k0_ * 4u : OOB_OFF); \
+        }                                                                                              \
+        _Pragma("unroll") for (int s = 0; s < B_IT; ++s)                                               \
+            rb[s] = buf_load4(rb_rsrc, (kin_ && b_off[s] != OOB_OFF) ? b_off[s] + k0_ * 4u : OOB_OFF); \
+    }
+#define KC_STORE(buf_)                                                                                 \
+    {                                                                                                  \
+        _Pragma("unroll") for (int s = 0; s < A_IT; ++s)                                               \
+            *reinterpret_cast<float4*>(As + (buf_) * BM * PITCH + (lr + 64 * s) * PITCH + lq * 4) = ra[s]; \
+        _Pragma("unroll") for (int s = 0; s < B_IT; ++s)                                               \
+            *reinterpret_cast<float4*>(Bs + (buf_) * BN * PITCH + (lr + 64 * s) * PITCH + lq * 4) = rb[s]; \
+    }
+
+    KC_LOAD(0)
+    KC_STORE(0)
     __syncthreads();
     const int frag_off = (lane & 31) * PITCH + (lane >> 5) * 4;
     for (int kc = 0; kc < nk; ++kc) {
         const int buf = kc & 1;
-        if (kc + 1 < nk) load_chunk(kc + 1);
+        if (kc + 1 < nk) KC_LOAD(kc + 1)
         const float* a_s = As + buf * BM * PITCH + wm * WM * PITCH + frag_off;
         const float* b_s = Bs + buf * BN * PITCH + wn * WN * PITCH + frag_off;
 #pragma unroll
@@ -158,36 +169,56 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KCParams p) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
                 }
         }
-        if (kc + 1 < nk) store_chunk(buf ^ 1);
+        if (kc + 1 < nk) KC_STORE(buf ^ 1)
         __syncthreads();
     }
+#undef KC_LOAD
+#undef KC_STORE
 
     // epilogue: lanes 0-31 of register r write 32 consecutive floats of one row (128 B)
     const int col0 = tile_n * BN + wn * WN + (lane & 31);
     const int row0 = tile_m * BM + wm * WM + 4 * (lane >> 5);
+    const bool plain = p.epi == 0 && p.res == nullptr;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = col0 + j * 32;
         if (col >= p.N) continue;
         const float bv = p.bias ? p.bias[col] : 0.f;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+        for (int i = 0; i < TM; ++i) {
+            if (plain) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
-                if (row >= p.M) continue;
-                float v = acc[i][j][r] + bv;
-                if (p.epi & EPI_STORE_PRE) p.aux[(size_t)row * p.ldaux + col] = v;
-                if (p.epi & EPI_ACT) v = act_fwd(p.act, v);
-                if (p.epi & EPI_MUL_DACT) v *= act_bwd(p.act, p.aux[(size_t)row * p.ldaux + col]);
-                if (p.res) v += p.res[(size_t)row * p.ldres + col];
-                p.C[(size_t)row * p.ldc + col] = v;
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                    if (row < p.M) p.C[(size_t)row * p.ldc + col] = acc[i][j][r] + bv;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                    if (row >= p.M) continue;
+                    float v = acc[i][j][r] + bv;
+                    if (p.epi & EPI_STORE_PRE) p.aux[(size_t)row * p.ldaux + col] = v;
+                    if (p.epi & EPI_ACT) v = act_fwd(p.act, v);
+                    if (p.epi & EPI_MUL_DACT) v *= act_bwd(p.act, p.aux[(size_t)row * p.ldaux + col]);
+                    if (p.res) v += p.res[(size_t)row * p.ldres + col];
+                    p.C[(size_t)row * p.ldc + col] = v;
+                }
             }
+        }
     }
 }
 
-static int launch_kc(const KCParams& p, bool im2col, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
+static int launch_kc(const KCParams& p_in, bool im2col, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
+    KCParams p = p_in;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return PA2D_OK;
+    {   // 32-bit byte offsets inside the buffer descriptors
+        const unsigned long long ab = ((unsigned long long)(p.M - 1) * p.lda + (im2col ? p.Cin : p.K)) * 4ull;
+        const unsigned long long bb = ((unsigned long long)(p.N - 1) * p.ldb + p.K) * 4ull;
+        if (ab >= 0xFFFFFFF0ull || bb >= 0xFFFFFFF0ull) return PA2D_ERR_UNSUPPORTED;
+        p.a_bytes = (unsigned)ab;
+        p.b_bytes = (unsigned)bb;
+    }
     if ((p.K & 3) || (p.lda & 3) || (p.ldb & 3)) return PA2D_ERR_ARG;
     if (im2col && ((p.Cin & 15) || p.K != 9 * p.Cin)) return PA2D_ERR_UNSUPPORTED;
     const int tiles_m = ceil_div(p.M, 128);
@@ -215,6 +246,7 @@ struct MCParams {
     float* slab;
     int Mk, chunks_per_split;
     int H, W, Cin;   // im2col view of B: image [B,H,W,Cin] with pixel pitch ldb, j = tap*Cin + ci
+    unsigned a_bytes, b_bytes;
 };
 
 template <int BM, int BN, bool IM2COL>
@@ -253,38 +285,39 @@ __global__ __launch_bounds__(256, 2) void gemm_mc_kernel(const MCParams p) {
     }
     const int HW = p.H * p.W;
 
+    const __amdgpu_buffer_rsrc_t ra_rsrc = make_rsrc(p.A, p.a_bytes);
+    const __amdgpu_buffer_rsrc_t rb_rsrc = make_rsrc(p.B, p.b_bytes);
+    const unsigned a_col = a_col_ok ? (unsigned)gi * 4u : OOB_OFF;
+    const unsigned b_col = b_col_ok ? (unsigned)(IM2COL ? ci : gj) * 4u : OOB_OFF;
+    const int tap_shift = tap_dy * p.W + tap_dx;
     float4 ra[A_IT], rb[B_IT];
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto load_chunk = [&](int c) {
-        const int m0 = c * BK;
-#pragma unroll
-        for (int s = 0; s < A_IT; ++s) {
-            const int m = m0 + a_r + s * A_RPP;
-            ra[s] = (a_col_ok && m < p.Mk) ? *reinterpret_cast<const float4*>(p.A + (size_t)m * p.lda + gi) : zero4;
-        }
-#pragma unroll
-        for (int s = 0; s < B_IT; ++s) {
-            const int m = m0 + b_r + s * B_RPP;
-            bool ok = b_col_ok && m < p.Mk;
-            if (IM2COL) {
-                const int n = m % HW;
-                const int y = n / p.W, x = n - y * p.W;
-                ok = ok && (unsigned)(y + tap_dy) < (unsigned)p.H && (unsigned)(x + tap_dx) < (unsigned)p.W;
-                const long long off = ((long long)m + tap_dy * p.W + tap_dx) * p.ldb + ci;
-                rb[s] = ok ? *reinterpret_cast<const float4*>(p.B + off) : zero4;
-            } else {
-                rb[s] = ok ? *reinterpret_cast<const float4*>(p.B + (size_t)m * p.ldb + gj) : zero4;
-            }
-        }
-    };
-    auto store_chunk = [&](int buf) {
-#pragma unroll
-        for (int s = 0; s < A_IT; ++s)
-            *reinterpret_cast<float4*>(As + buf * BK * BM + (a_r + s * A_RPP) * BM + a_c) = ra[s];
-#pragma unroll
-        for (int s = 0; s < B_IT; ++s)
-            *reinterpret_cast<float4*>(Bs + buf * BK * BN + (b_r + s * B_RPP) * BN + b_c) = rb[s];
-    };
+#define MC_LOAD(c_)                                                                                       \
+    {                                                                                                     \
+        const int m0_ = (c_) * BK;                                                                        \
+        _Pragma("unroll") for (int s = 0; s < A_IT; ++s) {                                                \
+            const int m_ = m0_ + a_r + s * A_RPP;                                                         \
+            ra[s] = buf_load4(ra_rsrc, (a_col != OOB_OFF && m_ < p.Mk) ? (unsigned)m_ * (unsigned)p.lda * 4u + a_col : OOB_OFF); \
+        }                                                                                                 \
+        _Pragma("unroll") for (int s = 0; s < B_IT; ++s) {                                                \
+            const int m_ = m0_ + b_r + s * B_RPP;                                                         \
+            bool ok_ = b_col != OOB_OFF && m_ < p.Mk;                                                     \
+            if (IM2COL) {                                                                                 \
+                const int n_ = m_ % HW;                                                                   \
+                const int y_ = n_ / p.W, x_ = n_ - y_ * p.W;                                              \
+                ok_ = ok_ && (unsigned)(y_ + tap_dy) < (unsigned)p.H && (unsigned)(x_ + tap_dx) < (unsigned)p.W; \
+                rb[s] = buf_load4(rb_rsrc, ok_ ? (unsigned)(m_ + tap_shift) * (unsigned)p.ldb * 4u + b_col : OOB_OFF); \
+            } else {                                                                                      \
+                rb[s] = buf_load4(rb_rsrc, ok_ ? (unsigned)m_ * (unsigned)p.ldb * 4u + b_col : OOB_OFF);  \
+            }                                                                                             \
+        }                                                                                                 \
+    }
+#define MC_STORE(buf_)                                                                                    \
+    {                                                                                                     \
+        _Pragma("unroll") for (int s = 0; s < A_IT; ++s)                                                  \
+            *reinterpret_cast<float4*>(As + (buf_) * BK * BM + (a_r + s * A_RPP) * BM + a_c) = ra[s];     \
+        _Pragma("unroll") for (int s = 0; s < B_IT; ++s)                                                  \
+            *reinterpret_cast<float4*>(Bs + (buf_) * BK * BN + (b_r + s * B_RPP) * BN + b_c) = rb[s];     \
+    }
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -295,14 +328,14 @@ __global__ __launch_bounds__(256, 2) void gemm_mc_kernel(const MCParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     if (c_begin < c_end) {
-        load_chunk(c_begin);
-        store_chunk(0);
+        MC_LOAD(c_begin)
+        MC_STORE(0)
     }
     __syncthreads();
     const int li = lane & 31, kh = lane >> 5;
     for (int c = c_begin; c < c_end; ++c) {
         const int buf = (c - c_begin) & 1;
-        if (c + 1 < c_end) load_chunk(c + 1);
+        if (c + 1 < c_end) MC_LOAD(c + 1)
         const float* a_s = As + buf * BK * BM + kh * BM + wm * WM + li;
         const float* b_s = Bs + buf * BK * BN + kh * BN + wn * WN + li;
 #pragma unroll
@@ -318,9 +351,11 @@ __global__ __launch_bounds__(256, 2) void gemm_mc_kernel(const MCParams p) {
                 for (int j = 0; j < TN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
-        if (c + 1 < c_end) store_chunk(buf ^ 1);
+        if (c + 1 < c_end) MC_STORE(buf ^ 1)
         __syncthreads();
     }
+#undef MC_LOAD
+#undef MC_STORE
 
     float* out = p.slab + (size_t)split * p.Mi * p.Nj;
     const int col0 = tj * BN + wn * WN + (lane & 31);
@@ -347,11 +382,21 @@ static MCPlan plan_mc(int Mi, int Nj, int Mk) {
     const int bm = pl.big ? 128 : 64;
     const int tiles = ceil_div(Mi, bm) * ceil_div(Nj, bm);
     const int total_chunks = ceil_div(Mk, 16);
-    int splits = ceil_div(1024, tiles);
+    // Every block is resident at once (<= 4 per CU), so the launch takes as long as the most loaded
+    // CU: pick the split count whose block total fills k*256 CU slots most evenly (k = 2..4),
+    // preferring fewer splits (less slab traffic) on ties.
     const int max_splits = total_chunks / 8 > 0 ? total_chunks / 8 : 1;   // >= 8 chunks per split
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    pl.chunks_per_split = ceil_div(total_chunks, splits);
+    int best = 1;
+    double best_eff = 0.0;
+    for (int k = 2; k <= 4; ++k) {
+        int sp = (256 * k) / tiles;
+        if (sp < 1) sp = 1;
+        if (sp > max_splits) sp = max_splits;
+        const int blocks = tiles * sp;
+        const double eff = (double)blocks / (256.0 * ceil_div(blocks, 256));
+        if (eff > best_eff + 0.02) { best_eff = eff; best = sp; }
+    }
+    pl.chunks_per_split = ceil_div(total_chunks, best);
     pl.splits = ceil_div(total_chunks, pl.chunks_per_split);
     pl.slab_floats = (size_t)pl.splits * Mi * Nj;
     return pl;
@@ -359,12 +404,30 @@ static MCPlan plan_mc(int Mi, int Nj, int Mk) {
 
 // out[idx] = sum_s slab[s][idx]; mode 1 additionally un-packs the conv weight gradient:
 // slab row-major [2C][9][Cin] -> dWx / dWf in the reference's [C_out][C_in][3][3] layout.
-__global__ void reduce_slabs_kernel(const float* __restrict__ slab, int nslab, long long count,
-                                    float* __restrict__ out, float* __restrict__ out2, int mode, int C, int Cin) {
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= count) return;
-    float s = 0.f;
-    for (int k = 0; k < nslab; ++k) s += slab[(size_t)k * count + idx];
+// 64 consecutive idx x 4 slab lanes per workgroup: each lane sums slabs s = lane, lane+4, ... with
+// 4 independent loads in flight; the 4 lane sums are added in fixed order (deterministic).
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slab, int nslab, long long count,
+                                                           float* __restrict__ out, float* __restrict__ out2,
+                                                           int mode, int C, int Cin) {
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const long long idx = (long long)blockIdx.x * 64 + tx;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (idx < count) {
+        const float* p = slab + idx;
+        int k = ty;
+        for (; k + 12 < nslab; k += 16) {
+            s0 += p[(size_t)k * count];
+            s1 += p[(size_t)(k + 4) * count];
+            s2 += p[(size_t)(k + 8) * count];
+            s3 += p[(size_t)(k + 12) * count];
+        }
+        for (; k < nslab; k += 4) s0 += p[(size_t)k * count];
+    }
+    red[ty][tx] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (ty != 0 || idx >= count) return;
+    const float s = ((red[0][tx] + red[1][tx]) + red[2][tx]) + red[3][tx];
     if (mode == 0) {
         out[idx] = s;
     } else {
@@ -383,6 +446,13 @@ static int launch_mc(const float* A, long long lda, int Mi, const float* B, long
     MCParams p;
     p.A = A; p.lda = lda; p.Mi = Mi; p.B = B; p.ldb = ldb; p.Nj = Nj; p.slab = slab; p.Mk = Mk;
     p.chunks_per_split = pl.chunks_per_split; p.H = H; p.W = W; p.Cin = Cin;
+    {
+        const unsigned long long ab = ((unsigned long long)(Mk - 1) * lda + Mi) * 4ull;
+        const unsigned long long bb = ((unsigned long long)(Mk - 1) * ldb + (im2col ? Cin : Nj)) * 4ull;
+        if (ab >= 0xFFFFFFF0ull || bb >= 0xFFFFFFF0ull) return PA2D_ERR_UNSUPPORTED;
+        p.a_bytes = (unsigned)ab;
+        p.b_bytes = (unsigned)bb;
+    }
     const int bm = pl.big ? 128 : 64;
     const dim3 grid(ceil_div(Mi, bm) * ceil_div(Nj, bm) * pl.splits);
     if (pl.big) {
@@ -398,9 +468,8 @@ static int launch_mc(const float* A, long long lda, int Mi, const float* B, long
 
 static int launch_reduce(const float* slab, int nslab, long long count, float* out, float* out2, int mode,
                          int C, int Cin, hipStream_t st) {
-    const int threads = 256;
-    const dim3 grid((unsigned)ceil_div_ll(count, threads));
-    hipLaunchKernelGGL(reduce_slabs_kernel, grid, dim3(threads), 0, st, slab, nslab, count, out, out2, mode, C, Cin);
+    const dim3 grid((unsigned)ceil_div_ll(count, 64));
+    hipLaunchKernelGGL(reduce_slabs_kernel, grid, dim3(256), 0, st, slab, nslab, count, out, out2, mode, C, Cin);
     PA2D_CHECK_LAUNCH();
     return PA2D_OK;
 }
@@ -416,9 +485,16 @@ __global__ void colsum_partial_kernel(const float* __restrict__ X, long long ld,
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(M, r0 + rows_per_block);
     for (int c = threadIdx.x; c < N; c += blockDim.x) {
-        float s = 0.f;
-        for (int r = r0; r < r1; ++r) s += X[(size_t)r * ld + c];
-        partial[(size_t)blockIdx.x * N + c] = s;
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+        int r = r0;
+        for (; r + 3 < r1; r += 4) {
+            s0 += X[(size_t)r * ld + c];
+            s1 += X[(size_t)(r + 1) * ld + c];
+            s2 += X[(size_t)(r + 2) * ld + c];
+            s3 += X[(size_t)(r + 3) * ld + c];
+        }
+        for (; r < r1; ++r) s0 += X[(size_t)r * ld + c];
+        partial[(size_t)blockIdx.x * N + c] = (s0 + s1) + (s2 + s3);
     }
 }
 
@@ -435,8 +511,9 @@ static int launch_colsum(const float* X, long long ld, int M, int N, float* out,
 // ---------------------------------------------------------------------------------------------
 // weight re-layouts (tiny; weights change every optimizer step so they are redone per call)
 // mode 0: plain transpose  dst[k][n] = src[n][k]                                  (linear bwd-data)
-// mode 1: conv fwd pack    dst[co'][tap][ci] = W_{co'<C ? x : f}[co][ci][tap]      ([2C][9*Cin])
-// mode 2: conv bwd pack    dst[ci][tap'][co'] = W_{..}[co][ci][8 - tap']           ([Cin][9*2C])
+// mode 1: conv fwd pack    dst[co'][cic][tap][c16] = W_{co'<C ? x : f}[co][cic*16+c16][tap]       ([2C][9*Cin])
+// mode 2: conv bwd pack    dst[ci][cic'][tap'][c16] = W_{..}[co = cic'*16+c16][ci][8 - tap']        ([Cin][9*2C])
+//         (K order of gemm_kc's implicit GEMM: 16-channel chunk outer, tap inner)
 __global__ void repack_kernel(const float* __restrict__ w0, const float* __restrict__ w1, float* __restrict__ dst,
                               int mode, int N, int K, int C, int Cin) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -446,16 +523,20 @@ __global__ void repack_kernel(const float* __restrict__ w0, const float* __restr
         dst[idx] = w0[(size_t)n * K + k];
     } else if (mode == 1) {
         if (idx >= (long long)2 * C * 9 * Cin) return;
-        const int ci = (int)(idx % Cin);
-        const int tap = (int)((idx / Cin) % 9);
+        const int c16 = (int)(idx % 16);
+        const int tap = (int)((idx / 16) % 9);
+        const int cic = (int)((idx / 144) % (Cin / 16));
         const int co = (int)(idx / ((long long)Cin * 9));
+        const int ci = cic * 16 + c16;
         const float* src = co < C ? w0 : w1;
         dst[idx] = src[((size_t)(co % C) * Cin + ci) * 9 + tap];
     } else {
         if (idx >= (long long)2 * C * 9 * Cin) return;
-        const int co = (int)(idx % (2 * C));
-        const int tap = (int)((idx / (2 * C)) % 9);
+        const int c16 = (int)(idx % 16);
+        const int tap = (int)((idx / 16) % 9);
+        const int cic = (int)((idx / 144) % (2 * C / 16));
         const int ci = (int)(idx / ((long long)2 * C * 9));
+        const int co = cic * 16 + c16;
         const float* src = co < C ? w0 : w1;
         dst[idx] = src[((size_t)(co % C) * Cin + ci) * 9 + (8 - tap)];
     }
