@@ -1,0 +1,107 @@
+"""CPU: the oracle (oracle/transolver_oracle.py) against the golden vectors the REFERENCE produced
+(tests/golden/*.npz, written by oracle/make_golden.py in the build container).  This is what pins
+the oracle; the GPU tests then pin the HIP path against the same vectors and against the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, rel_l2
+from oracle import transolver_oracle as orc
+from transformerbasednavierstokesolver_amd import synth
+
+
+def _sample(t, n=257):
+    f = torch.as_tensor(t).detach().double().numpy().ravel()
+    stride = max(1, f.size // n)
+    return f[::stride][:n]
+
+
+@pytest.mark.parametrize("tag,dtype,tol", [("f64", torch.float64, 1e-12), ("f32", torch.float32, 2e-5)])
+def test_g1_tiny_forward_loss_and_all_grads(tag, dtype, tol):
+    g = np.load(os.path.join(GOLDEN, "G1_tiny.npz"))
+    cfg = synth.TINY_CONFIG
+    sd = orc.to_torch({k[3:]: g[k] for k in g.files if k.startswith("sd.")}, dtype, requires_grad=True)
+    x, fx, y = (torch.from_numpy(g[k]).to(dtype) for k in ("x", "fx", "y"))
+    pred = orc.model_forward(sd, x, fx, cfg)
+    assert rel_l2(pred, g[f"pred.{tag}"]) < tol
+    loss = orc.rel_l2(pred.reshape(2, -1), y.reshape(2, -1))
+    assert abs(loss.item() - float(g[f"loss.{tag}"])) < 50 * tol * abs(float(g[f"loss.{tag}"]))
+    loss.backward()
+    assert sd["placeholder"].grad is None            # unused on the fx-given path (…_2D.py:205-210)
+    for k in sd:
+        if k != "placeholder":
+            assert rel_l2(sd[k].grad, g[f"grad.{tag}.{k}"]) < 50 * tol, k
+
+
+def test_g1_clamp_mask_is_pinned():
+    """temperatures outside [0.1, 5] (Physics_Attention.py:99) get exactly zero gradient."""
+    g = np.load(os.path.join(GOLDEN, "G1_tiny.npz"))
+    t = g["sd.blocks.0.Attn.temperature"].reshape(-1)
+    gr = g["grad.f64.blocks.0.Attn.temperature"].reshape(-1)
+    outside = (t < 0.1) | (t > 5.0)
+    assert outside.any() and (~outside).any()
+    assert np.all(gr[outside] == 0) and np.all(gr[~outside] != 0)
+
+
+def test_g1b_fx_none_and_time_branches():
+    g = np.load(os.path.join(GOLDEN, "G1b_tiny_branches.npz"))
+    cfg = dict(synth.TINY_CONFIG, fun_dim=0, Time_Input=True, unified_pos=0)
+    sd = orc.to_torch(synth.synth_state_dict(cfg, seed=12))
+    pred = orc.model_forward(sd, torch.from_numpy(g["x"]), None, cfg, T=torch.from_numpy(g["T"]).reshape(-1, 1))
+    assert rel_l2(pred, g["pred"]) < 2e-5
+
+
+def test_g2_attention_module_ns_shape_forward():
+    g = np.load(os.path.join(GOLDEN, "G2_attn_ns.npz"))
+    cfg = synth.NS_CONFIG
+    sd = orc.to_torch({k: v for k, v in synth.synth_state_dict(dict(cfg, n_layers=1), seed=21).items()
+                       if k.startswith("blocks.0.Attn.")}, torch.float64)
+    rng = np.random.default_rng(22)
+    x = torch.from_numpy(rng.standard_normal((1, 4096, cfg["n_hidden"])).astype(np.float32)).double()
+    y = orc.physics_attention(x, sd, "blocks.0.Attn.", 64, 64, cfg["n_head"])
+    assert rel_l2(_sample(y), g["y.sample"]) < 1e-12
+    assert abs(float(y.norm()) - float(g["y.norm"])) < 1e-10 * float(g["y.norm"])
+
+
+def test_g3_shipped_checkpoint_rollout_first_frames():
+    """The reference's own trained weights (checkpoints/ep400_sim100.pt as npz data)."""
+    g = np.load(os.path.join(GOLDEN, "G3_shipped_rollout.npz"))
+    ck = np.load(os.path.join(GOLDEN, "ckpt_ep400_sim100.npz"))
+    sd = orc.to_torch({k: ck[k] for k in ck.files}, torch.float64)
+    assert len(sd) == 169 and sum(v.numel() for v in sd.values()) == 714753
+    pos, a, _ = synth.ns_batch(2, seed=31)
+    fr = orc.rollout(sd, torch.from_numpy(pos).double(), torch.from_numpy(a).double(), synth.NS_SMALL_CONFIG, 5)
+    for t in (0, 4):
+        assert rel_l2(_sample(fr[..., t]), g[f"frame{t + 1}.f64.sample"]) < 1e-11
+
+
+def test_g5_full_ns_forward():
+    g = np.load(os.path.join(GOLDEN, "G5_full_ns.npz"))
+    cfg = synth.NS_CONFIG
+    sd = orc.to_torch(synth.synth_state_dict(cfg, seed=51), torch.float64)
+    pos, a, _ = synth.ns_batch(1, seed=52)
+    with torch.no_grad():
+        pred = orc.model_forward(sd, torch.from_numpy(pos).double(), torch.from_numpy(a).double(), cfg)
+    assert rel_l2(pred.reshape(-1), g["pred"]) < 1e-12
+
+
+def test_hand_derived_backward_matches_autograd():
+    """SURVEY Appendix A.2 formulas (used to test the HIP backward stage by stage) vs autograd."""
+    B, N, h, D, M = 2, 37, 4, 8, 12
+    C = h * D
+    rng = np.random.default_rng(3)
+    r = lambda *s: torch.from_numpy(rng.standard_normal(s)).double()
+    xm, fm, dy = r(B, N, C), r(B, N, C), r(B, N, C)
+    ws, bs = r(M, D) * 0.4, r(M) * 0.3
+    temp = torch.tensor([0.03, 0.5, 7.0, 1.5], dtype=torch.float64)
+    wq, wk, wv = r(D, D) * 0.5, r(D, D) * 0.5, r(D, D) * 0.5
+    leaves = [t.requires_grad_(True) for t in (xm, fm, ws, bs, temp, wq, wk, wv)]
+    w, norm, s, tok = orc.slice_tokens(xm, fm, ws, bs, temp, h)
+    y = orc.deslice(w, orc.token_attention(tok, wq, wk, wv))
+    grads = torch.autograd.grad(y, leaves, dy)
+    ref = orc.slice_core_backward(xm.detach(), fm.detach(), dy, ws.detach(), bs.detach(), temp.detach(),
+                                  wq.detach(), wk.detach(), wv.detach(), h)
+    for name, gr in zip(("dxm", "dfm", "dws", "dbs", "dtemperature", "dwq", "dwk", "dwv"), grads):
+        assert rel_l2(ref[name].reshape(gr.shape), gr) < 1e-12, name

@@ -142,7 +142,7 @@ def meshgrid_pos(S, H, W):
     y = np.linspace(0, 1, H)
     xx, yy = np.meshgrid(x, y)
     pos = np.stack([xx.ravel(), yy.ravel()], axis=-1).astype(np.float32)
-    return np.ascontiguousarray(np.broadcast_to(pos[None], (S, H * W, 2)))
+    return np.array(np.broadcast_to(pos[None], (S, H * W, 2)))   # writable copy
 
 
 def ns_batch(S, H=64, W=64, T_in=10, T=10, seed=0):
