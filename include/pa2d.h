@@ -34,6 +34,13 @@ enum pa2d_act { PA2D_ACT_NONE = 0, PA2D_ACT_GELU = 1, PA2D_ACT_TANH = 2, PA2D_AC
 
 const char* pa2d_version(void);
 
+/* Process-wide engine selection for the conv implicit GEMMs (also env PA2D_GEMM=f32|split at first use):
+ * 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), the default and what bench.py measures;
+ * 1 = experimental: operands split into 3 bf16 terms, 6 bf16 MFMA terms per product, fp32 accumulate
+ *     (fp32-level accuracy, same parity tolerances). */
+void pa2d_set_gemm_mode(int mode);
+int pa2d_get_gemm_mode(void);
+
 /* ---- LayerNorm: nn.LayerNorm(C) of Transolver_block, model/Transolver_Structured_Mesh_2D.py:58,62,65,70-73 */
 int pa2d_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
                        float* rstd, int rows, int C, float eps, pa2d_stream_t stream);

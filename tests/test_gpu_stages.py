@@ -183,3 +183,18 @@ def test_head(dev, rows, C, O):
     assert rel_l2(dx, dy.double() @ w.double()) < BWD_TOL
     assert rel_l2(dw, dy.double().t() @ x.double()) < BWD_TOL
     assert rel_l2(db, dy.double().sum(0)) < BWD_TOL
+
+
+def test_conv_split_bf16_engine_meets_fp32_tolerances(dev):
+    """Experimental engine (pa2d_set_gemm_mode(1)): 3-way bf16 operand split, 6 MFMA terms, fp32
+    accumulate — must meet the SAME fp32 tolerances as the exact fp32 MFMA engine."""
+    from transformerbasednavierstokesolver_amd import _lib
+    lib = _lib.load()
+    lib.pa2d_set_gemm_mode(1)
+    try:
+        assert lib.pa2d_get_gemm_mode() == 1
+        for args in ((2, 6, 5, 32), (2, 64, 64, 256), (1, 21, 17, 128)):
+            test_conv3x3x2(dev, *args)
+    finally:
+        lib.pa2d_set_gemm_mode(0)
+    assert lib.pa2d_get_gemm_mode() == 0

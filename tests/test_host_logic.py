@@ -118,7 +118,7 @@ def _header_functions():
     txt = open(os.path.join(ROOT, "include", "pa2d.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     out = {}
-    for m in re.finditer(r"\b(?:int|size_t|const char\*)\s+(pa2d_\w+)\s*\(([^;]*?)\)\s*;", txt, flags=re.S):
+    for m in re.finditer(r"\b(?:int|void|size_t|const char\*)\s+(pa2d_\w+)\s*\(([^;]*?)\)\s*;", txt, flags=re.S):
         args = m.group(2).strip()
         out[m.group(1)] = 0 if args in ("", "void") else len(args.split(","))
     return out

@@ -21,6 +21,8 @@ _st = C.c_void_p     # hipStream_t
 # name -> (restype, argtypes); mirrors include/pa2d.h one to one
 SIGNATURES = {
     "pa2d_version": (C.c_char_p, []),
+    "pa2d_set_gemm_mode": (None, [_i]),
+    "pa2d_get_gemm_mode": (_i, []),
     "pa2d_layernorm_fwd": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, C.c_float, _st]),
     "pa2d_layernorm_bwd_workspace": (_sz, [_i, _i]),
     "pa2d_layernorm_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _sz, _i, _i, _st]),

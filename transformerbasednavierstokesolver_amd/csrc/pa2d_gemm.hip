@@ -23,6 +23,7 @@
 // element t of both fragments, i.e. MFMA-k {0,1} <-> real k {8kk+t, 8kk+4+t}: any permutation of k
 // is fine as long as A and B use the same one.
 #include "pa2d_internal.h"
+#include <stdlib.h>
 
 #define EPI_ACT 1        // out = act(acc + bias)
 #define EPI_STORE_PRE 2  // aux = acc + bias   (pre-activation, saved for backward)
@@ -209,6 +210,233 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KCParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// gemm_kc_split: the same contraction as gemm_kc on the bf16 matrix cores at fp32 accuracy.
+// gfx950 has no xf32/TF32 path and its f32 MFMA runs at 1/16 of the bf16 MFMA rate, so each fp32
+// operand is split exactly into three bf16 terms  x = hi + mid + lo (+ <=2^-25 |x|)  while it is
+// staged into LDS, and every product is evaluated as the six terms of order <= 2
+//     hi.hi + hi.mid + mid.hi + hi.lo + lo.hi + mid.mid
+// with v_mfma_f32_32x32x16_bf16 accumulating in fp32 (dropped terms are <= 2^-24 relative, the same
+// order as the fp32 rounding of one product).  6 bf16 MFMAs of K=16 (192 cycles) replace 8 fp32
+// MFMAs of K=2 (512 cycles) per 32x32x16 block.  Numerics are checked by the same parity tests and
+// tolerances as the fp32 engine.
+// LDS row = [hi(64 B) | mid(64 B) | lo(64 B) | pad 16 B] for 32 k: pitch 208 B = 13 x 16 B, an odd
+// number of 16-byte slots, so the ds_read_b128 fragment reads (lane l: row l&31, k-half l>>5) of every
+// 16-lane group hit 16 different slots.  One LDS stage (53 KB/workgroup, 3 workgroups per CU): the
+// next K-step's global loads are issued before the MFMAs of the current one and converted after them.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split3(const float4 v, bf16x4& hi, bf16x4& mid, bf16x4& lo) {
+    const float xs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const __bf16 h = (__bf16)xs[i];
+        const float r1 = xs[i] - (float)h;
+        const __bf16 m = (__bf16)r1;
+        const float r2 = r1 - (float)m;
+        hi[i] = h; mid[i] = m; lo[i] = (__bf16)r2;
+    }
+}
+
+// Wave-specialised workgroup of 8 waves (one producer + one consumer wave per SIMD, so the VALU
+// conversion work and the matrix pipe run concurrently):
+//   waves 4-7 (producers): buffer-load the fp32 A/B tiles of K-step k+1, split them, write LDS stage
+//                          (k+1)&1, then put the loads of K-step k+2 in flight;
+//   waves 0-3 (consumers): 48 MFMAs per K-step on stage k&1 (2x2 tiles of 32x32, 2 k-halves, 6 terms).
+// One __syncthreads per K-step hands stage (k+1)&1 over and frees stage k&1.
+template <int BM, int BN, bool IM2COL>
+__global__ __launch_bounds__(512, 2) void gemm_kc_split_kernel(const KCParams p) {
+    constexpr int BK = 32, PITCHB = 208;                 // bytes per LDS row (3 planes x 64 B + 16)
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int A_IT = BM / 32, B_IT = BN / 32;        // float4 per producer thread per K-step
+    constexpr int STAGE = (BM + BN) * PITCHB;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int tmx = (tiles_m + 7) / 8;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tile_m = xcd * tmx + slot / tiles_n;
+    const int tile_n = slot % tiles_n;
+    if (tile_m >= tiles_m || slot / tiles_n >= tmx) return;
+    const int nk = (p.K + BK - 1) / BK;
+    const bool producer = wave >= 4;                     // wave-uniform
+
+    if (producer) {
+        const int ptid = tid - 256;
+        const int lr = ptid >> 3, lq = ptid & 7;         // 8 lanes cover one 128-byte row segment
+        const __amdgpu_buffer_rsrc_t ra_rsrc = make_rsrc(p.A, p.a_bytes);
+        const __amdgpu_buffer_rsrc_t rb_rsrc = make_rsrc(p.B, p.b_bytes);
+        unsigned a_off[A_IT], b_off[B_IT];
+        int a_y[A_IT], a_x[A_IT];
+#pragma unroll
+        for (int s = 0; s < A_IT; ++s) {
+            const int gm = tile_m * BM + lr + 32 * s;
+            a_off[s] = gm < p.M ? (unsigned)gm * (unsigned)p.lda * 4u + lq * 16u : OOB_OFF;
+            if (IM2COL) {
+                const int n = gm % (p.H * p.W);
+                a_y[s] = n / p.W;
+                a_x[s] = n - a_y[s] * p.W;
+            } else {
+                a_y[s] = a_x[s] = 0;
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < B_IT; ++s) {
+            const int gn = tile_n * BN + lr + 32 * s;
+            b_off[s] = gn < p.N ? (unsigned)gn * (unsigned)p.ldb * 4u + lq * 16u : OOB_OFF;
+        }
+        float4 ra[A_IT], rb[B_IT];
+#define KS_LOAD(kc_)                                                                                   \
+    {                                                                                                  \
+        const int k0_ = (kc_) * BK;                                                                    \
+        const bool kin_ = k0_ + lq * 4 < p.K;                                                          \
+        if (IM2COL) {                                                                                  \
+            const int cic_ = (kc_) / 9, tap_ = (kc_) - cic_ * 9;                                       \
+            const int dy_ = tap_ / 3 - 1, dx_ = tap_ - (tap_ / 3) * 3 - 1;                             \
+            const int sh_ = ((dy_ * p.W + dx_) * (int)p.lda + cic_ * BK) * 4;                          \
+            _Pragma("unroll") for (int s = 0; s < A_IT; ++s) {                                         \
+                const bool ok_ = (unsigned)(a_y[s] + dy_) < (unsigned)p.H &&                           \
+                                 (unsigned)(a_x[s] + dx_) < (unsigned)p.W && a_off[s] != OOB_OFF;      \
+                ra[s] = buf_load4(ra_rsrc, ok_ ? a_off[s] + (unsigned)sh_ : OOB_OFF);                  \
+            }                                                                                          \
+        } else {                                                                                       \
+            _Pragma("unroll") for (int s = 0; s < A_IT; ++s)                                           \
+                ra[s] = buf_load4(ra_rsrc, (kin_ && a_off[s] != OOB_OFF) ? a_off[s] + k0_ * 4u : OOB_OFF); \
+        }                                                                                              \
+        _Pragma("unroll") for (int s = 0; s < B_IT; ++s)                                               \
+            rb[s] = buf_load4(rb_rsrc, (kin_ && b_off[s] != OOB_OFF) ? b_off[s] + k0_ * 4u : OOB_OFF); \
+    }
+#define KS_STORE(buf_)                                                                                 \
+    {                                                                                                  \
+        unsigned char* const As_ = smem + (buf_) * STAGE;                                              \
+        unsigned char* const Bs_ = As_ + BM * PITCHB;                                                  \
+        _Pragma("unroll") for (int s = 0; s < A_IT; ++s) {                                             \
+            bf16x4 h_, m_, l_;                                                                         \
+            split3(ra[s], h_, m_, l_);                                                                 \
+            unsigned char* d_ = As_ + (lr + 32 * s) * PITCHB + lq * 8;                                 \
+            *reinterpret_cast<bf16x4*>(d_) = h_;                                                       \
+            *reinterpret_cast<bf16x4*>(d_ + 64) = m_;                                                  \
+            *reinterpret_cast<bf16x4*>(d_ + 128) = l_;                                                 \
+        }                                                                                              \
+        _Pragma("unroll") for (int s = 0; s < B_IT; ++s) {                                             \
+            bf16x4 h_, m_, l_;                                                                         \
+            split3(rb[s], h_, m_, l_);                                                                 \
+            unsigned char* d_ = Bs_ + (lr + 32 * s) * PITCHB + lq * 8;                                 \
+            *reinterpret_cast<bf16x4*>(d_) = h_;                                                       \
+            *reinterpret_cast<bf16x4*>(d_ + 64) = m_;                                                  \
+            *reinterpret_cast<bf16x4*>(d_ + 128) = l_;                                                 \
+        }                                                                                              \
+    }
+        KS_LOAD(0)
+        KS_STORE(0)
+        if (nk > 1) KS_LOAD(1)
+        __syncthreads();
+        for (int kc = 0; kc < nk; ++kc) {
+            if (kc + 1 < nk) {
+                KS_STORE((kc + 1) & 1)
+                if (kc + 2 < nk) KS_LOAD(kc + 2)
+            }
+            __syncthreads();
+        }
+#undef KS_LOAD
+#undef KS_STORE
+        return;
+    }
+
+    // ---------------- consumers
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int frag_off = (lane & 31) * PITCHB + (lane >> 5) * 16;
+    __syncthreads();
+    for (int kc = 0; kc < nk; ++kc) {
+        const unsigned char* a_s = smem + (kc & 1) * STAGE + wm * WM * PITCHB + frag_off;
+        const unsigned char* b_s = smem + (kc & 1) * STAGE + BM * PITCHB + wn * WN * PITCHB + frag_off;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[TM][3], bf[TN][3];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    af[i][q] = *reinterpret_cast<const bf16x8*>(a_s + i * 32 * PITCHB + q * 64 + ks * 32);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    bf[j][q] = *reinterpret_cast<const bf16x8*>(b_s + j * 32 * PITCHB + q * 64 + ks * 32);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    // smallest terms first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();
+    }
+
+    const int col0 = tile_n * BN + wn * WN + (lane & 31);
+    const int row0 = tile_m * BM + wm * WM + 4 * (lane >> 5);
+    const bool plain = p.epi == 0 && p.res == nullptr;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = col0 + j * 32;
+        if (col >= p.N) continue;
+        const float bv = p.bias ? p.bias[col] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            if (plain) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                    if (row < p.M) p.C[(size_t)row * p.ldc + col] = acc[i][j][r] + bv;
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                    if (row >= p.M) continue;
+                    float v = acc[i][j][r] + bv;
+                    if (p.epi & EPI_STORE_PRE) p.aux[(size_t)row * p.ldaux + col] = v;
+                    if (p.epi & EPI_ACT) v = act_fwd(p.act, v);
+                    if (p.epi & EPI_MUL_DACT) v *= act_bwd(p.act, p.aux[(size_t)row * p.ldaux + col]);
+                    if (p.res) v += p.res[(size_t)row * p.ldres + col];
+                    p.C[(size_t)row * p.ldc + col] = v;
+                }
+            }
+        }
+    }
+}
+
+// engine selection: PA2D_GEMM=f32 (v_mfma_f32_32x32x2_f32) or split (6-term bf16 split, fp32 accuracy)
+static int g_gemm_mode = -1;   // process-wide tuning knob (pa2d_set_gemm_mode / env PA2D_GEMM), default f32
+static int gemm_mode_split() {
+    if (g_gemm_mode < 0) {
+        const char* e = getenv("PA2D_GEMM");
+        g_gemm_mode = (e && e[0] == 's') ? 1 : 0;
+    }
+    return g_gemm_mode;
+}
+// chunk (channels per tap step) the conv weight packs must use for the selected engine
+// the experimental split engine is only used for the conv implicit GEMMs (it is slower than the f32
+// engine on the short-K linears)
+static bool use_split(int N, bool im2col, int Cin) { return gemm_mode_split() && im2col && N > 64 && (Cin % 32) == 0; }
+static int conv_chunk(int Cin, int N) { return use_split(N, true, Cin) ? 32 : 16; }
+
 static int launch_kc(const KCParams& p_in, bool im2col, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
     KCParams p = p_in;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return PA2D_OK;
@@ -223,7 +451,22 @@ static int launch_kc(const KCParams& p_in, bool im2col, hipStream_t st, hipEvent
     if (im2col && ((p.Cin & 15) || p.K != 9 * p.Cin)) return PA2D_ERR_UNSUPPORTED;
     const int tiles_m = ceil_div(p.M, 128);
     if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return PA2D_ERR_ARG;
-    if (p.N > 64) {
+    if (use_split(p.N, im2col, p.Cin)) {
+        const int tiles_n = ceil_div(p.N, 128);
+        const dim3 grid(ceil_div(tiles_m, 8) * 8 * tiles_n);
+        const int smem = 2 * (128 + 128) * 208;
+        static bool attr_done = false;
+        if (!attr_done) {
+            hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kc_split_kernel<128, 128, true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kc_split_kernel<128, 128, false>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            if (e1 != hipSuccess || e2 != hipSuccess) return (int)(e1 != hipSuccess ? e1 : e2);
+            attr_done = true;
+        }
+        if (im2col) hipLaunchKernelGGL((gemm_kc_split_kernel<128, 128, true>), grid, dim3(512), smem, st, p);
+        else hipLaunchKernelGGL((gemm_kc_split_kernel<128, 128, false>), grid, dim3(512), smem, st, p);
+    } else if (p.N > 64) {
         const int tiles_n = ceil_div(p.N, 128);
         const dim3 grid(ceil_div(tiles_m, 8) * 8 * tiles_n);
         if (im2col) hipLaunchKernelGGL((gemm_kc_kernel<128, 128, 2, 2, true>), grid, dim3(256), 0, st, p);
@@ -338,19 +581,35 @@ __global__ __launch_bounds__(256, 2) void gemm_mc_kernel(const MCParams p) {
         if (c + 1 < c_end) MC_LOAD(c + 1)
         const float* a_s = As + buf * BK * BM + kh * BM + wm * WM + li;
         const float* b_s = Bs + buf * BK * BN + kh * BN + wn * WN + li;
+        // fragments of k-step kk+1 are fetched into the other register set before the MFMAs of
+        // k-step kk issue, so the LDS latency hides behind 4 x 64 MFMA cycles
+        float af[2][TM], bf[2][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[0][i] = a_s[i * 32];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[0][j] = b_s[j * 32];
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
-            float af[TM], bf[TN];
+            if (kk + 1 < BK / 2) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = a_s[kk * 2 * BM + i * 32];
+                for (int i = 0; i < TM; ++i) af[(kk + 1) & 1][i] = a_s[(kk + 1) * 2 * BM + i * 32];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = b_s[kk * 2 * BN + j * 32];
+                for (int j = 0; j < TN; ++j) bf[(kk + 1) & 1][j] = b_s[(kk + 1) * 2 * BN + j * 32];
+            }
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk & 1][i], bf[kk & 1][j], acc[i][j], 0, 0, 0);
         }
+        // pin the interleave: reads(0); { reads(kk+1); mfma(kk) } x 7; mfma(7)   (0x100 = DS read, 0x8 = MFMA)
+        __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+#pragma unroll
+        for (int kk = 0; kk < BK / 2 - 1; ++kk) {
+            __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
         if (c + 1 < c_end) MC_STORE(buf ^ 1)
         __syncthreads();
     }
@@ -388,7 +647,9 @@ static MCPlan plan_mc(int Mi, int Nj, int Mk) {
     const int max_splits = total_chunks / 8 > 0 ? total_chunks / 8 : 1;   // >= 8 chunks per split
     int best = 1;
     double best_eff = 0.0;
-    for (int k = 2; k <= 4; ++k) {
+    const char* env_k = getenv("PA2D_MC_K");      // tuning knob: force k blocks per CU
+    const int k_lo = env_k ? atoi(env_k) : 2, k_hi = env_k ? atoi(env_k) : 4;
+    for (int k = k_hi; k >= k_lo; --k) {      // ties -> more workgroups per CU (better latency hiding)
         int sp = (256 * k) / tiles;
         if (sp < 1) sp = 1;
         if (sp > max_splits) sp = max_splits;
@@ -523,20 +784,22 @@ __global__ void repack_kernel(const float* __restrict__ w0, const float* __restr
         dst[idx] = w0[(size_t)n * K + k];
     } else if (mode == 1) {
         if (idx >= (long long)2 * C * 9 * Cin) return;
-        const int c16 = (int)(idx % 16);
-        const int tap = (int)((idx / 16) % 9);
-        const int cic = (int)((idx / 144) % (Cin / 16));
+        const int CH = K;      // channels per K-step (16 for the f32 engine, 32 for the split engine)
+        const int c16 = (int)(idx % CH);
+        const int tap = (int)((idx / CH) % 9);
+        const int cic = (int)((idx / (9 * CH)) % (Cin / CH));
         const int co = (int)(idx / ((long long)Cin * 9));
-        const int ci = cic * 16 + c16;
+        const int ci = cic * CH + c16;
         const float* src = co < C ? w0 : w1;
         dst[idx] = src[((size_t)(co % C) * Cin + ci) * 9 + tap];
     } else {
         if (idx >= (long long)2 * C * 9 * Cin) return;
-        const int c16 = (int)(idx % 16);
-        const int tap = (int)((idx / 16) % 9);
-        const int cic = (int)((idx / 144) % (2 * C / 16));
+        const int CH = K;
+        const int c16 = (int)(idx % CH);
+        const int tap = (int)((idx / CH) % 9);
+        const int cic = (int)((idx / (9 * CH)) % (2 * C / CH));
         const int ci = (int)(idx / ((long long)2 * C * 9));
-        const int co = cic * 16 + c16;
+        const int co = cic * CH + c16;
         const float* src = co < C ? w0 : w1;
         dst[idx] = src[((size_t)(co % C) * Cin + ci) * 9 + (8 - tap)];
     }
@@ -554,6 +817,10 @@ static int launch_repack(const float* w0, const float* w1, float* dst, int mode,
 // =============================================================================================
 // C ABI (declared in include/pa2d.h)
 extern "C" {
+
+// 0 = exact fp32 MFMA engine (default), 1 = experimental 6-term bf16-split engine for the conv GEMMs
+void pa2d_set_gemm_mode(int mode) { g_gemm_mode = mode ? 1 : 0; }
+int pa2d_get_gemm_mode(void) { return gemm_mode_split(); }
 
 int pa2d_gemm_bias_act_fwd(const float* x, long long ldx, const float* w, long long ldw, const float* bias,
                            const float* res, long long ldres, float* y, long long ldy, float* pre, long long ldpre,
@@ -615,7 +882,7 @@ int pa2d_conv3x3x2_fwd(const float* xn, const float* wx, const float* bx, const 
                        int C, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (ws_bytes < (size_t)2 * C * 9 * C * sizeof(float)) return PA2D_ERR_WORKSPACE;
     float* pack = (float*)ws;
-    int rc = launch_repack(wx, wf, pack, 1, 0, 0, C, C, st);
+    int rc = launch_repack(wx, wf, pack, 1, 0, conv_chunk(C, 2 * C), C, C, st);
     if (rc) return rc;
     hipError_t e = hipMemcpyAsync(bias2_ws, bx, C * sizeof(float), hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) return (int)e;
@@ -638,7 +905,7 @@ int pa2d_conv3x3x2_bwd(const float* dout, const float* xn, const float* wx, cons
     const int M = B * H * W;
     int rc;
     if (dxn) {
-        rc = launch_repack(wx, wf, pack, 2, 0, 0, C, C, st);
+        rc = launch_repack(wx, wf, pack, 2, 0, conv_chunk(2 * C, C), C, C, st);
         if (rc) return rc;
         KCParams p = {};
         p.A = dout; p.lda = 2 * C; p.B = pack; p.ldb = 9 * 2 * C; p.C = dxn; p.ldc = C;

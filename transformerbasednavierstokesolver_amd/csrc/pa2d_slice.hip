@@ -32,20 +32,30 @@ struct SCfg {
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+// Reductions across the 16 lanes of a DPP row (lanes 16g..16g+15) with VALU-DPP operands instead
+// of ds_bpermute: quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror.  After the
+// four steps every lane of the row holds the row result.
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float row16_max(float v) {
-    v = fmaxf(v, __shfl_xor(v, 1, 64));
-    v = fmaxf(v, __shfl_xor(v, 2, 64));
-    v = fmaxf(v, __shfl_xor(v, 4, 64));
-    v = fmaxf(v, __shfl_xor(v, 8, 64));
+    v = fmaxf(v, dpp_mov<0xB1>(v));
+    v = fmaxf(v, dpp_mov<0x4E>(v));
+    v = fmaxf(v, dpp_mov<0x141>(v));
+    v = fmaxf(v, dpp_mov<0x140>(v));
     return v;
 }
 __device__ __forceinline__ float row16_sum(float v) {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
     return v;
 }
+// exp(x) for x <= 0 (softmax after max subtraction) on the hardware exponential: 2^(x*log2 e).
+// Relative error ~1e-7 near 0 where the weights matter, growing only for terms that are ~0 anyway.
+__device__ __forceinline__ float fast_exp(float x) { return __builtin_amdgcn_exp2f(x * 1.44269504088896340736f); }
 __device__ __forceinline__ float kq_max(float v) {   // across the 4 lane groups l, l^16, l^32, l^48
     v = fmaxf(v, __shfl_xor(v, 16, 64));
     v = fmaxf(v, __shfl_xor(v, 32, 64));
@@ -142,7 +152,7 @@ __global__ __launch_bounds__(256) void slice_scatter_kernel(const SliceParams p)
             float sm = 0.f;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                const float e = expf(w[mt][r] - mx);
+                const float e = fast_exp(w[mt][r] - mx);
                 w[mt][r] = e;
                 sm += e;
             }
@@ -255,7 +265,7 @@ __global__ __launch_bounds__(256) void deslice_kernel(const DesliceParams p) {
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float e = expf(w[mt][r] - mx);
+                const float e = fast_exp(w[mt][r] - mx);
                 w[mt][r] = e;
                 sm += e;
             }
@@ -412,7 +422,7 @@ __global__ __launch_bounds__(256) void slice_bwd_kernel(const SliceBwdParams p) 
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float e = expf(z[mt][r] - mx);
+                const float e = fast_exp(z[mt][r] - mx);
                 w[mt][r] = e;
                 sm += e;
             }
