@@ -57,7 +57,11 @@ def main():
     tests["conv_fwd"] = (lambda: ops.conv3x3x2_fwd(xn, wx, bx, wf, bf, H, W), conv_flops, "TF")
     tests["conv_bwd"] = (lambda: ops.conv3x3x2_bwd(dout2, xn, wx, wf, H, W), 2 * conv_flops, "TF")
     tests["conv_bwd_wonly"] = (lambda: ops.conv3x3x2_bwd(dout2, xn, wx, wf, H, W, need_dx=False), conv_flops, "TF")
-    tests["linear_fwd"] = (lambda: ops.linear_fwd(x2d, w, bias, res=res, act="gelu", want_pre=True), lin_flops, "TF")
+    tests["linear_fwd"] = (lambda: ops.linear_fwd(x2d, w, bias, act="gelu", want_pre=True), lin_flops, "TF")   # MLP1
+    tests["linear_plain"] = (lambda: ops.linear_fwd(x2d, w), lin_flops, "TF")
+    tests["linear_bias_res"] = (lambda: ops.linear_fwd(x2d, w, bias, res=res), lin_flops, "TF")
+    tests["linear_gelu"] = (lambda: ops.linear_fwd(x2d, w, bias, act="gelu"), lin_flops, "TF")
+    tests["linear_bwd_plain"] = (lambda: ops.linear_bwd_data(dy2d, w), lin_flops, "TF")
     tests["linear_bwd_data"] = (lambda: ops.linear_bwd_data(dy2d, w, pre=x2d, act="gelu"), lin_flops, "TF")
     tests["linear_bwd_weight"] = (lambda: ops.linear_bwd_weight(dy2d, x2d), lin_flops, "TF")
     y, mean, rstd = ops.layernorm_fwd(x2d, gamma, beta)

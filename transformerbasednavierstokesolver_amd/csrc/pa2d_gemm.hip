@@ -40,6 +40,7 @@ struct KCParams {
     int act, epi;
     int H, W, Cin;   // im2col view: A = image [B,H,W,Cin] with pixel pitch lda, K = 9*Cin
     unsigned a_bytes, b_bytes;   // extents of A and B for the buffer descriptors (filled by launch_kc)
+    unsigned c_bytes, res_bytes, aux_bytes;
 };
 
 // Raw buffer loads: lanes whose byte offset is >= num_records return 0 from the hardware range
@@ -54,6 +55,74 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, u
 __device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff) {
     const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
+}
+__device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned voff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, 0, 0);
+}
+__device__ __forceinline__ float gelu_f(float x) { return gelu_exact(x); }
+__device__ __forceinline__ float dgelu_f(float x) { return dgelu_exact(x); }
+
+// Branch-free epilogue of one 32x32 accumulator tile.  Ragged rows / columns are masked by the buffer
+// range check (masked lanes get offset OOB_OFF: loads return 0, stores are dropped); all residual /
+// pre-activation loads of the tile are issued before the first use.  ACT_ID < 0: runtime p.act.
+template <bool HAS_RES, bool STORE_PRE, bool ACT, bool DACT, int ACT_ID>
+__device__ __forceinline__ void kc_epilogue_tile(const KCParams& p, const f32x16& acc, int row_base, int col,
+                                                 __amdgpu_buffer_rsrc_t rc, __amdgpu_buffer_rsrc_t rres,
+                                                 __amdgpu_buffer_rsrc_t raux) {
+    const bool col_ok = col < p.N;
+    const float bv = (p.bias && col_ok) ? p.bias[col] : 0.f;
+    unsigned offc[16];
+    float rv[16], av[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = row_base + (r & 3) + 8 * (r >> 2);
+        const bool ok = col_ok && row < p.M;
+        offc[r] = ok ? ((unsigned)row * (unsigned)p.ldc + (unsigned)col) * 4u : OOB_OFF;
+        if (HAS_RES) rv[r] = buf_load1(rres, ok ? ((unsigned)row * (unsigned)p.ldres + (unsigned)col) * 4u : OOB_OFF);
+        if (DACT) av[r] = buf_load1(raux, ok ? ((unsigned)row * (unsigned)p.ldaux + (unsigned)col) * 4u : OOB_OFF);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = row_base + (r & 3) + 8 * (r >> 2);
+        float v = acc[r] + bv;
+        if (STORE_PRE)
+            buf_store1(raux, offc[r] != OOB_OFF ? ((unsigned)row * (unsigned)p.ldaux + (unsigned)col) * 4u : OOB_OFF, v);
+        if (ACT) v = ACT_ID == ACT_GELU ? gelu_f(v) : act_fwd(p.act, v);
+        if (DACT) v *= ACT_ID == ACT_GELU ? dgelu_f(av[r]) : act_bwd(p.act, av[r]);
+        if (HAS_RES) v += rv[r];
+        buf_store1(rc, offc[r], v);
+    }
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void kc_epilogue(const KCParams& p, f32x16 (&acc)[TM][TN], int row0, int col0) {
+    const __amdgpu_buffer_rsrc_t rc = make_rsrc(p.C, p.c_bytes);
+    const __amdgpu_buffer_rsrc_t rres = make_rsrc(p.res ? p.res : p.C, p.res ? p.res_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t raux = make_rsrc(p.aux ? p.aux : p.C, p.aux ? p.aux_bytes : 0u);
+    const bool has_res = p.res != nullptr;
+    const bool gelu = p.act == ACT_GELU;
+#define KC_EPI(HR, SP, AC, DA, ID)                                                                     \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) _Pragma("unroll") for (int i = 0; i < TM; ++i)      \
+        kc_epilogue_tile<HR, SP, AC, DA, ID>(p, acc[i][j], row0 + i * 32, col0 + j * 32, rc, rres, raux);
+    if (p.epi == 0) {
+        if (has_res) { KC_EPI(true, false, false, false, 0) } else { KC_EPI(false, false, false, false, 0) }
+    } else if (p.epi == (EPI_ACT | EPI_STORE_PRE) && gelu && !has_res) {
+        KC_EPI(false, true, true, false, ACT_GELU)
+    } else if (p.epi == EPI_MUL_DACT && gelu && !has_res) {
+        KC_EPI(false, false, false, true, ACT_GELU)
+    } else {   // generic: any flag combination / activation (off the hot path)
+        const bool sp = p.epi & EPI_STORE_PRE, ac = p.epi & EPI_ACT, da = p.epi & EPI_MUL_DACT;
+        if (da) { if (has_res) { KC_EPI(true, false, false, true, -1) } else { KC_EPI(false, false, false, true, -1) } }
+        else if (sp && ac) { if (has_res) { KC_EPI(true, true, true, false, -1) } else { KC_EPI(false, true, true, false, -1) } }
+        else if (ac) { if (has_res) { KC_EPI(true, false, true, false, -1) } else { KC_EPI(false, false, true, false, -1) } }
+        else { if (has_res) { KC_EPI(true, true, false, false, -1) } else { KC_EPI(false, true, false, false, -1) } }
+    }
+#undef KC_EPI
 }
 
 template <int BM, int BN, int WAVES_M, int WAVES_N, bool IM2COL>
@@ -177,37 +246,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KCParams p) {
 #undef KC_STORE
 
     // epilogue: lanes 0-31 of register r write 32 consecutive floats of one row (128 B)
-    const int col0 = tile_n * BN + wn * WN + (lane & 31);
-    const int row0 = tile_m * BM + wm * WM + 4 * (lane >> 5);
-    const bool plain = p.epi == 0 && p.res == nullptr;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = col0 + j * 32;
-        if (col >= p.N) continue;
-        const float bv = p.bias ? p.bias[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            if (plain) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
-                    if (row < p.M) p.C[(size_t)row * p.ldc + col] = acc[i][j][r] + bv;
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
-                    if (row >= p.M) continue;
-                    float v = acc[i][j][r] + bv;
-                    if (p.epi & EPI_STORE_PRE) p.aux[(size_t)row * p.ldaux + col] = v;
-                    if (p.epi & EPI_ACT) v = act_fwd(p.act, v);
-                    if (p.epi & EPI_MUL_DACT) v *= act_bwd(p.act, p.aux[(size_t)row * p.ldaux + col]);
-                    if (p.res) v += p.res[(size_t)row * p.ldres + col];
-                    p.C[(size_t)row * p.ldc + col] = v;
-                }
-            }
-        }
-    }
+    kc_epilogue<TM, TN>(p, acc, tile_m * BM + wm * WM + 4 * (lane >> 5), tile_n * BN + wn * WN + (lane & 31));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -389,37 +428,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kc_split_kernel(const KCParams p)
         __syncthreads();
     }
 
-    const int col0 = tile_n * BN + wn * WN + (lane & 31);
-    const int row0 = tile_m * BM + wm * WM + 4 * (lane >> 5);
-    const bool plain = p.epi == 0 && p.res == nullptr;
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = col0 + j * 32;
-        if (col >= p.N) continue;
-        const float bv = p.bias ? p.bias[col] : 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            if (plain) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
-                    if (row < p.M) p.C[(size_t)row * p.ldc + col] = acc[i][j][r] + bv;
-                }
-            } else {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
-                    if (row >= p.M) continue;
-                    float v = acc[i][j][r] + bv;
-                    if (p.epi & EPI_STORE_PRE) p.aux[(size_t)row * p.ldaux + col] = v;
-                    if (p.epi & EPI_ACT) v = act_fwd(p.act, v);
-                    if (p.epi & EPI_MUL_DACT) v *= act_bwd(p.act, p.aux[(size_t)row * p.ldaux + col]);
-                    if (p.res) v += p.res[(size_t)row * p.ldres + col];
-                    p.C[(size_t)row * p.ldc + col] = v;
-                }
-            }
-        }
-    }
+    kc_epilogue<TM, TN>(p, acc, tile_m * BM + wm * WM + 4 * (lane >> 5), tile_n * BN + wn * WN + (lane & 31));
 }
 
 // engine selection: PA2D_GEMM=f32 (v_mfma_f32_32x32x2_f32) or split (6-term bf16 split, fp32 accuracy)
@@ -446,6 +455,11 @@ static int launch_kc(const KCParams& p_in, bool im2col, hipStream_t st, hipEvent
         if (ab >= 0xFFFFFFF0ull || bb >= 0xFFFFFFF0ull) return PA2D_ERR_UNSUPPORTED;
         p.a_bytes = (unsigned)ab;
         p.b_bytes = (unsigned)bb;
+        const unsigned long long cb = ((unsigned long long)(p.M - 1) * p.ldc + p.N) * 4ull;
+        const unsigned long long rb = p.res ? ((unsigned long long)(p.M - 1) * p.ldres + p.N) * 4ull : 0ull;
+        const unsigned long long xb = p.aux ? ((unsigned long long)(p.M - 1) * p.ldaux + p.N) * 4ull : 0ull;
+        if (cb >= 0xFFFFFFF0ull || rb >= 0xFFFFFFF0ull || xb >= 0xFFFFFFF0ull) return PA2D_ERR_UNSUPPORTED;
+        p.c_bytes = (unsigned)cb; p.res_bytes = (unsigned)rb; p.aux_bytes = (unsigned)xb;
     }
     if ((p.K & 3) || (p.lda & 3) || (p.ldb & 3)) return PA2D_ERR_ARG;
     if (im2col && ((p.Cin & 15) || p.K != 9 * p.Cin)) return PA2D_ERR_UNSUPPORTED;

@@ -21,9 +21,32 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 enum { ACT_NONE = 0, ACT_GELU = 1, ACT_TANH = 2, ACT_SIGMOID = 3, ACT_RELU = 4, ACT_SOFTPLUS = 5,
        ACT_ELU = 6, ACT_SILU = 7 };
 
+// Exact-erf GELU (nn.GELU() default) without ocml erff: Phi(x) = 0.5*(1+erf(x/sqrt2)) from the
+// Abramowitz-Stegun 7.1.26 rational form q(z) = (a1 t + ... + a5 t^5) exp(-z^2), t = 1/(1+p z),
+// erfc(z) = q(z) + eps, |eps| <= 1.5e-7 (fp32 level), evaluated branch-free on z = |x|/sqrt2.
+// e_out returns exp(-x^2/2) so the derivative can reuse it for the density term.
+__device__ __forceinline__ float normal_cdf(float x, float& e_out) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-z * z * 1.44269504088896340736f);
+    e_out = e;
+    const float hq = 0.5f * poly * t * e;          // 0.5 * erfc(z)
+    return x < 0.f ? hq : 1.0f - hq;
+}
+__device__ __forceinline__ float gelu_exact(float x) { float e; return x * normal_cdf(x, e); }
+__device__ __forceinline__ float dgelu_exact(float x) {
+    float e;
+    const float cdf = normal_cdf(x, e);
+    return fmaf(x * 0.39894228040143267794f, e, cdf);
+}
+
 __device__ __forceinline__ float act_fwd(int id, float x) {
     switch (id) {
-        case ACT_GELU: return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+        case ACT_GELU: return gelu_exact(x);
         case ACT_TANH: return tanhf(x);
         case ACT_SIGMOID: return 1.0f / (1.0f + expf(-x));
         case ACT_RELU: return x > 0.f ? x : 0.f;
@@ -37,11 +60,7 @@ __device__ __forceinline__ float act_fwd(int id, float x) {
 // d act(x) / dx evaluated at the pre-activation x
 __device__ __forceinline__ float act_bwd(int id, float x) {
     switch (id) {
-        case ACT_GELU: {
-            const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-            const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
-            return cdf + x * pdf;
-        }
+        case ACT_GELU: return dgelu_exact(x);
         case ACT_TANH: { const float t = tanhf(x); return 1.0f - t * t; }
         case ACT_SIGMOID: { const float s = 1.0f / (1.0f + expf(-x)); return s * (1.0f - s); }
         case ACT_RELU: return x > 0.f ? 1.f : 0.f;
