@@ -115,10 +115,19 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with `python -m torch.distributed.run --nproc-per-node N`")
+    ndev = torch.cuda.device_count()
+    if world > 1 and os.environ.get("PA2D_DIST_BACKEND", "nccl") != "nccl":
+        local_rank = local_rank % max(ndev, 1)       # rehearsal mode: ranks share the visible GPU(s)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        # "nccl" is RCCL on ROCm.  PA2D_DIST_BACKEND=gloo exists only to rehearse the N>1 code path on a
+        # box with a single GPU (several ranks sharing cuda:0); it is never used for reported numbers.
+        backend = os.environ.get("PA2D_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     cfg = synth.NS_CONFIG
     B = args.batch_per_gpu

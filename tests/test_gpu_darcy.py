@@ -1,0 +1,109 @@
+"""Large-N stress case of BASELINE configs[4]: Darcy 421x421 structured mesh (N = 177 241 points),
+C=128, 8 heads (D=16), M=128 slices, exp_darcy.py:118-130 geometry.  The CPU oracle needs minutes at
+this size, so the checker is the oracle's own torch code evaluated in fp64 ON THE GPU (an
+implementation independent of libpa2d: ATen/rocBLAS), with the 3x3 conv written as 9 shifted matmuls
+because MIOpen has no fp64 convolution.  Same fp32 tolerances as the small cases."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def conv3x3_shifted(x_bnc, w, b, H, W):
+    """zero-padded 3x3 cross-correlation on [B, H*W, C] as 9 shifted GEMMs (any dtype/device)."""
+    B, N, C = x_bnc.shape
+    img = torch.nn.functional.pad(x_bnc.reshape(B, H, W, C), (0, 0, 1, 1, 1, 1))
+    out = b.reshape(1, 1, 1, -1).expand(B, H, W, -1).clone()
+    for ky in range(3):
+        for kx in range(3):
+            out = out + img[:, ky:ky + H, kx:kx + W, :] @ w[:, :, ky, kx].t()
+    return out.reshape(B, N, -1)
+
+
+@pytest.fixture()
+def oracle_on_gpu(monkeypatch):
+    from oracle import transolver_oracle as orc
+    monkeypatch.setattr(orc, "conv3x3", conv3x3_shifted)
+    monkeypatch.setattr(orc, "unified_pos", lambda H, W, ref, dtype=torch.float32: _pos(H, W, ref, dtype))
+    return orc
+
+
+_POS_CACHE = {}
+
+
+def _pos(H, W, ref, dtype):
+    from oracle import transolver_oracle as orc_real
+    key = (H, W, ref)
+    if key not in _POS_CACHE:
+        import importlib
+        gy = torch.tensor(np.linspace(0, 1, H), dtype=torch.float32)
+        gx = torch.tensor(np.linspace(0, 1, W), dtype=torch.float32)
+        ry = torch.tensor(np.linspace(0, 1, ref), dtype=torch.float32)
+        rx = torch.tensor(np.linspace(0, 1, ref), dtype=torch.float32)
+        d0 = gy[:, None, None, None] - ry[None, None, :, None]
+        d1 = gx[None, :, None, None] - rx[None, None, None, :]
+        _POS_CACHE[key] = torch.sqrt(d0 ** 2 + d1 ** 2).reshape(1, H * W, ref * ref)
+    return _POS_CACHE[key].to(DEV).to(dtype)
+
+
+def test_darcy_421_attention_forward_backward(oracle_on_gpu):
+    orc = oracle_on_gpu
+    from transformerbasednavierstokesolver_amd import synth
+    from transformerbasednavierstokesolver_amd.model.Physics_Attention import Physics_Attention_Structured_Mesh_2D
+    H = W = 421
+    C, h, M = 128, 8, 128
+    cfg = synth.make_config(n_layers=1, n_hidden=C, n_head=h, slice_num=M, fun_dim=1, H=H, W=W)
+    sd_all = synth.synth_state_dict(cfg, seed=71)
+    pre = "blocks.0.Attn."
+    sd = {k[len(pre):]: torch.from_numpy(v) for k, v in sd_all.items() if k.startswith(pre)}
+    a = Physics_Attention_Structured_Mesh_2D(C, heads=h, dim_head=C // h, slice_num=M, H=H, W=W)
+    a.load_state_dict(sd, strict=True)
+    a = a.to(DEV)
+    g = torch.Generator(device=DEV).manual_seed(72)
+    x = torch.randn(1, H * W, C, device=DEV, generator=g).requires_grad_(True)
+    gy = torch.randn(1, H * W, C, device=DEV, generator=g)
+    y = a(x)
+    y.backward(gy)
+    sdo = {pre + k: v.to(DEV).double().requires_grad_(True) for k, v in sd.items()}
+    xo = x.detach().double().requires_grad_(True)
+    yo = orc.physics_attention(xo, sdo, pre, H, W, h)
+    yo.backward(gy.double())
+    assert rel_l2(y, yo) < 5e-6
+    assert rel_l2(x.grad, xo.grad) < 5e-5
+    for k, p in a.named_parameters():
+        tol = 2e-3 if ("to_q" in k or "to_k" in k) else 1e-4
+        assert rel_l2(p.grad, sdo[pre + k].grad) < tol, k
+
+
+def test_darcy_421_model_training_step(oracle_on_gpu):
+    """exp_darcy.py:209-234 shape of one iteration: single model call (fun_dim=1), rel-L2, backward."""
+    orc = oracle_on_gpu
+    from transformerbasednavierstokesolver_amd import synth, harness
+    from transformerbasednavierstokesolver_amd.utils.testloss import TestLoss
+    H = W = 421
+    cfg = synth.make_config(n_layers=2, n_hidden=128, n_head=8, slice_num=128, fun_dim=1, out_dim=1, H=H, W=W)
+    sd = synth.synth_state_dict(cfg, seed=73)
+    m = harness.build_model(cfg, sd, DEV)
+    g = torch.Generator(device=DEV).manual_seed(74)
+    x = torch.zeros(1, H * W, 2, device=DEV)
+    fx = torch.randn(1, H * W, 1, device=DEV, generator=g)
+    yy = torch.randn(1, H * W, 1, device=DEV, generator=g)
+    pred = m(x, fx)
+    loss = TestLoss(size_average=False)(pred.reshape(1, -1), yy.reshape(1, -1))
+    loss.backward()
+    sdo = {k: torch.from_numpy(v).to(DEV).double().requires_grad_(True) for k, v in sd.items()}
+    po = orc.model_forward(sdo, x.double(), fx.double(), cfg)
+    lo = orc.rel_l2(po.reshape(1, -1), yy.double().reshape(1, -1))
+    lo.backward()
+    assert rel_l2(pred, po) < 1e-5
+    assert abs(loss.item() - lo.item()) < 1e-5 * abs(lo.item())
+    for k, p in m.named_parameters():
+        if k == "placeholder":
+            assert p.grad is None
+            continue
+        tol = 2e-3 if ("to_q" in k or "to_k" in k) else 1e-4
+        assert rel_l2(p.grad, sdo[k].grad) < tol, k

@@ -480,16 +480,27 @@ static int launch_kc(const KCParams& p_in, bool im2col, hipStream_t st, hipEvent
         }
         if (im2col) hipLaunchKernelGGL((gemm_kc_split_kernel<128, 128, true>), grid, dim3(512), smem, st, p);
         else hipLaunchKernelGGL((gemm_kc_split_kernel<128, 128, false>), grid, dim3(512), smem, st, p);
-    } else if (p.N > 64) {
-        const int tiles_n = ceil_div(p.N, 128);
-        const dim3 grid(ceil_div(tiles_m, 8) * 8 * tiles_n);
-        if (im2col) hipLaunchKernelGGL((gemm_kc_kernel<128, 128, 2, 2, true>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((gemm_kc_kernel<128, 128, 2, 2, false>), grid, dim3(256), 0, st, p);
     } else {
-        const int tiles_n = ceil_div(p.N, 64);
-        const dim3 grid(ceil_div(tiles_m, 8) * 8 * tiles_n);
-        if (im2col) hipLaunchKernelGGL((gemm_kc_kernel<128, 64, 4, 1, true>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((gemm_kc_kernel<128, 64, 4, 1, false>), grid, dim3(256), 0, st, p);
+        // tile choice: 128x128 when that already gives >= 1.5 workgroups per CU, otherwise smaller tiles
+        // so that small problems (rollout at batch 1: M = 4096) still fill the 256 CUs
+        const long long t128 = (long long)tiles_m * ceil_div(p.N, 128);
+        const long long t12864 = (long long)tiles_m * ceil_div(p.N, 64);
+        if (p.N > 64 && t128 >= 384) {
+            const int tiles_n = ceil_div(p.N, 128);
+            const dim3 grid(ceil_div(tiles_m, 8) * 8 * tiles_n);
+            if (im2col) hipLaunchKernelGGL((gemm_kc_kernel<128, 128, 2, 2, true>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((gemm_kc_kernel<128, 128, 2, 2, false>), grid, dim3(256), 0, st, p);
+        } else if (t12864 >= 384 || p.M <= 64) {
+            const int tiles_n = ceil_div(p.N, 64);
+            const dim3 grid(ceil_div(tiles_m, 8) * 8 * tiles_n);
+            if (im2col) hipLaunchKernelGGL((gemm_kc_kernel<128, 64, 4, 1, true>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((gemm_kc_kernel<128, 64, 4, 1, false>), grid, dim3(256), 0, st, p);
+        } else {
+            const int tm64 = ceil_div(p.M, 64), tiles_n = ceil_div(p.N, 64);
+            const dim3 grid(ceil_div(tm64, 8) * 8 * tiles_n);
+            if (im2col) hipLaunchKernelGGL((gemm_kc_kernel<64, 64, 2, 2, true>), grid, dim3(256), 0, st, p);
+            else hipLaunchKernelGGL((gemm_kc_kernel<64, 64, 2, 2, false>), grid, dim3(256), 0, st, p);
+        }
     }
     PA2D_CHECK_LAUNCH();
     if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return PA2D_ERR_ARG;
