@@ -512,7 +512,7 @@ struct MCParams {
     const float* A; long long lda; int Mi;
     const float* B; long long ldb; int Nj;
     float* slab;
-    int Mk, chunks_per_split;
+    int Mk, chunks_per_split, splits;
     int H, W, Cin;   // im2col view of B: image [B,H,W,Cin] with pixel pitch ldb, j = tap*Cin + ci
     unsigned a_bytes, b_bytes;
 };
@@ -530,9 +530,24 @@ __global__ __launch_bounds__(256, 2) void gemm_mc_kernel(const MCParams p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int tiles_i = (p.Mi + BM - 1) / BM, tiles_j = (p.Nj + BN - 1) / BN;
-    const int tj = blockIdx.x % tiles_j;
-    const int ti = (blockIdx.x / tiles_j) % tiles_i;
-    const int split = blockIdx.x / (tiles_i * tiles_j);
+    // XCD-aware map (speed only): when the split count is a multiple of 8, blocks b, b+8, ... (one XCD
+    // under round-robin dispatch) own a contiguous range of splits = a contiguous range of rows m, so
+    // each XCD's L2 streams 1/8 of the operands instead of all of them.
+    int tj, ti, split;
+    {
+        const int tiles = tiles_i * tiles_j;
+        if ((p.splits & 7) == 0) {
+            const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, q = p.splits >> 3;
+            split = xcd * q + slot / tiles;
+            const int t = slot % tiles;
+            tj = t % tiles_j;
+            ti = t / tiles_j;
+        } else {
+            tj = blockIdx.x % tiles_j;
+            ti = (blockIdx.x / tiles_j) % tiles_i;
+            split = blockIdx.x / tiles;
+        }
+    }
     const int wm = wave >> 1, wn = wave & 1;
 
     const int total_chunks = (p.Mk + BK - 1) / BK;
@@ -666,22 +681,28 @@ static MCPlan plan_mc(int Mi, int Nj, int Mk) {
     const int bm = pl.big ? 128 : 64;
     const int tiles = ceil_div(Mi, bm) * ceil_div(Nj, bm);
     const int total_chunks = ceil_div(Mk, 16);
-    // Every block is resident at once (<= 4 per CU), so the launch takes as long as the most loaded
-    // CU: pick the split count whose block total fills k*256 CU slots most evenly (k = 2..4),
-    // preferring fewer splits (less slab traffic) on ties.
+    // Split counts are multiples of 8 (one contiguous split range per XCD, see the kernel).  At most 4
+    // workgroups per CU are resident, the rest run as slots free up, so the efficiency of a block
+    // total is blocks / (256 * ceil(blocks/256)); take the smallest multiple of 8 that reaches
+    // >= 0.97 with at least 2 workgroups per CU (fewer splits = less slab traffic; measured on the conv
+    // weight gradient: 8/16/24/32 splits -> 3.63/3.02/2.84/2.75 ms).
     const int max_splits = total_chunks / 8 > 0 ? total_chunks / 8 : 1;   // >= 8 chunks per split
-    int best = 1;
-    double best_eff = 0.0;
-    const char* env_k = getenv("PA2D_MC_K");      // tuning knob: force k blocks per CU
-    const int k_lo = env_k ? atoi(env_k) : 2, k_hi = env_k ? atoi(env_k) : 4;
-    for (int k = k_hi; k >= k_lo; --k) {      // ties -> more workgroups per CU (better latency hiding)
-        int sp = (256 * k) / tiles;
-        if (sp < 1) sp = 1;
-        if (sp > max_splits) sp = max_splits;
-        const int blocks = tiles * sp;
-        const double eff = (double)blocks / (256.0 * ceil_div(blocks, 256));
-        if (eff > best_eff + 0.02) { best_eff = eff; best = sp; }
+    int best = max_splits < 8 ? max_splits : 8;
+    const char* env_s = getenv("PA2D_MC_SPLITS");                           // tuning knob
+    if (env_s) {
+        best = atoi(env_s);
+    } else if (max_splits >= 8) {
+        double best_eff = 0.0;
+        for (int sp = 8; sp <= max_splits && sp <= 512; sp += 8) {
+            const int blocks = tiles * sp;
+            if (blocks < 512 && sp + 8 <= max_splits) continue;
+            const double eff = (double)blocks / (256.0 * ceil_div(blocks, 256));
+            if (eff > best_eff + 1e-9) { best_eff = eff; best = sp; }
+            if (eff >= 0.97) { best = sp; break; }
+        }
     }
+    if (best < 1) best = 1;
+    if (best > max_splits) best = max_splits;
     pl.chunks_per_split = ceil_div(total_chunks, best);
     pl.splits = ceil_div(total_chunks, pl.chunks_per_split);
     pl.slab_floats = (size_t)pl.splits * Mi * Nj;
@@ -731,7 +752,7 @@ static int launch_mc(const float* A, long long lda, int Mi, const float* B, long
     if (im2col && (Cin & 3)) return PA2D_ERR_UNSUPPORTED;
     MCParams p;
     p.A = A; p.lda = lda; p.Mi = Mi; p.B = B; p.ldb = ldb; p.Nj = Nj; p.slab = slab; p.Mk = Mk;
-    p.chunks_per_split = pl.chunks_per_split; p.H = H; p.W = W; p.Cin = Cin;
+    p.chunks_per_split = pl.chunks_per_split; p.splits = pl.splits; p.H = H; p.W = W; p.Cin = Cin;
     {
         const unsigned long long ab = ((unsigned long long)(Mk - 1) * lda + Mi) * 4ull;
         const unsigned long long bb = ((unsigned long long)(Mk - 1) * ldb + (im2col ? Cin : Nj)) * 4ull;
