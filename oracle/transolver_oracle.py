@@ -26,6 +26,8 @@ Reference lines each function follows (relative to the reference repo root):
   train_iteration        exp_ns.py:191-218
   rollout                exp_ns.py:225-241, ns_vorticity_unrolling.py:264-286
   timestep_embedding     model/Embedding.py:67-85
+  unrolled_iteration_loss  ns_vorticity_unrolling.py:225-244
+  central_diff, darcy_loss exp_darcy.py:59-68, 216-227
 """
 from __future__ import annotations
 
@@ -244,6 +246,42 @@ def rollout(sd, x, fx, cfg, nsteps, step=1):
         frames.append(im)
         fx = torch.cat((fx[..., step:], im), dim=-1)
     return torch.cat(frames, -1)
+
+
+def unrolled_iteration_loss(sd, x, fx, yy, cfg, look_ahead, step=1):
+    """ns_vorticity_unrolling.py:225-244: windows of `look_ahead` chained calls, loss on the last
+    prediction of each window, window advanced with ground truth."""
+    T = yy.shape[-1]
+    B = x.shape[0]
+    offset = step * look_ahead
+    loss = 0.0
+    for t in range(0, T - look_ahead + 1, look_ahead):
+        y = yy[..., t + offset - step:t + offset]
+        im = sol_forward(sd, x, fx, cfg, look_ahead, step)
+        loss = loss + rel_l2(im.reshape(B, -1), y.reshape(B, -1))
+        fx = torch.cat((fx[..., look_ahead:], yy[..., t:t + look_ahead]), dim=-1)
+    return loss
+
+
+def central_diff(x, h, res):
+    """exp_darcy.py:59-68"""
+    B, N, C = x.shape
+    img = F.pad(x.reshape(B, res, res, C), (0, 0, 1, 1, 1, 1))
+    return ((img[:, 1:-1, 2:] - img[:, 1:-1, :-2]) / (2 * h), (img[:, 2:, 1:-1] - img[:, :-2, 1:-1]) / (2 * h))
+
+
+def darcy_loss(out, y, mean, std, dx, s):
+    """exp_darcy.py:216-227 with UnitTransformer.decode (utils/normalizer.py:52-53)."""
+    out, y = out * std + mean, y * std + mean
+    l2 = rel_l2(out, y)
+    B = out.shape[0]
+    mask = torch.zeros(s, s, dtype=out.dtype)
+    mask[1:-1, 1:-1] = 1
+    inner = (out.reshape(B, s, s) * mask).reshape(B, s * s, 1)
+    gx, gy = central_diff(y.unsqueeze(-1), dx, s)
+    px, py = central_diff(inner, dx, s)
+    deriv = rel_l2(px, gx) + rel_l2(py, gy)
+    return 0.1 * deriv + l2, l2, deriv
 
 
 # ----------------------------------------------------------------------------- A.2 backward (hand-derived)

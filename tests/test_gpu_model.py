@@ -177,3 +177,63 @@ def test_sol_wrapper_bptt_matches_oracle():
         if k == "placeholder":
             continue
         assert rel_l2(p.grad, sdo[k].grad) < _grad_tol(k), k
+
+
+def test_unrolled_lookahead_training_iteration_matches_oracle():
+    """ns_vorticity_unrolling.py:225-244 through the SOL wrapper (look_ahead=2, BPTT through 2 calls)."""
+    from transformerbasednavierstokesolver_amd import synth, harness
+    from transformerbasednavierstokesolver_amd.model.SOL_Transolver_Structured_Mesh_2D import SOL_Transolver_Structured_Mesh_2D
+    from oracle import transolver_oracle as orc
+    cfg = dict(synth.TINY_CONFIG, out_dim=1, fun_dim=4)
+    sd = synth.synth_state_dict(cfg, seed=81)
+    kw = {k: cfg[k] for k in ("space_dim", "n_layers", "n_hidden", "dropout", "n_head", "Time_Input", "act", "mlp_ratio",
+                              "fun_dim", "out_dim", "slice_num", "ref", "unified_pos", "H", "W")}
+    sol = SOL_Transolver_Structured_Mesh_2D(**kw, step=1, look_ahead=1)
+    sol.transolver_model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    sol = sol.to(DEV)
+    rng = np.random.default_rng(82)
+    N = cfg["H"] * cfg["W"]
+    x = torch.from_numpy(rng.standard_normal((2, N, 2)).astype(np.float32))
+    fx = torch.from_numpy(rng.standard_normal((2, N, 4)).astype(np.float32))
+    yy = torch.from_numpy(rng.standard_normal((2, N, 4)).astype(np.float32))
+    loss = harness.unrolled_train_iteration(sol, x.to(DEV), fx.to(DEV), yy.to(DEV), look_ahead=2)
+    loss.backward()
+    sdo = orc.to_torch(sd, torch.float64, requires_grad=True)
+    lo = orc.unrolled_iteration_loss(sdo, x.double(), fx.double(), yy.double(), cfg, 2)
+    lo.backward()
+    assert abs(loss.item() - lo.item()) < 1e-5 * abs(lo.item())
+    for k, p in sol.transolver_model.named_parameters():
+        if k != "placeholder":
+            assert rel_l2(p.grad, sdo[k].grad) < _grad_tol(k), k
+    cur = harness.LookAheadCurriculum(epochs=8, look_ahead=1, max_look_ahead=10)
+    assert [cur.update(ep) for ep in range(8)] == [1, 1, 1, 1, 2, 2, 4, 8]
+
+
+def test_darcy_iteration_matches_oracle():
+    """exp_darcy.py:209-234 on a small grid: decode, rel-L2 + 0.1 x derivative loss, backward."""
+    from transformerbasednavierstokesolver_amd import synth, harness
+    from transformerbasednavierstokesolver_amd.utils.normalizer import UnitTransformer
+    from oracle import transolver_oracle as orc
+    s = 9
+    cfg = synth.make_config(n_layers=2, n_hidden=32, n_head=4, slice_num=16, fun_dim=1, out_dim=1, ref=3, H=s, W=s)
+    sd = synth.synth_state_dict(cfg, seed=91)
+    m = harness.build_model(cfg, sd, DEV)
+    rng = np.random.default_rng(92)
+    x = torch.zeros(3, s * s, 2)
+    fx = torch.from_numpy(rng.standard_normal((3, s * s)).astype(np.float32))
+    y_raw = torch.from_numpy((2.0 + 0.5 * rng.standard_normal((3, s * s))).astype(np.float32))
+    norm = UnitTransformer(y_raw)
+    y = norm.encode(y_raw)
+    dx = 1.0 / s
+    out = m(x.to(DEV), fx=fx.to(DEV).unsqueeze(-1)).squeeze(-1)
+    loss, l2, deriv = harness.darcy_loss(out, y.to(DEV), norm.to(DEV), dx, s)
+    loss.backward()
+    sdo = orc.to_torch(sd, torch.float64, requires_grad=True)
+    oo = orc.model_forward(sdo, x.double(), fx.double().unsqueeze(-1), cfg).squeeze(-1)
+    lo, l2o, dvo = orc.darcy_loss(oo, y.double(), norm.mean.cpu().double(), norm.std.cpu().double(), dx, s)
+    lo.backward()
+    assert abs(loss.item() - lo.item()) < 2e-5 * abs(lo.item())
+    assert abs(deriv.item() - dvo.item()) < 2e-5 * abs(dvo.item())
+    for k, p in m.named_parameters():
+        if k != "placeholder":
+            assert rel_l2(p.grad, sdo[k].grad) < _grad_tol(k), k

@@ -9,6 +9,10 @@ so they cannot be imported; these functions reproduce their loops:
                                 (prediction-feedback loop, no grad)
   GraphedRollout                the same step captured once in a hipGraph (static buffers; the
                                 `torch.cat` window shift becomes an in-place roll)
+  unrolled_train_iteration      ns_vorticity_unrolling.py:225-244 (look-ahead windows through the SOL
+  / LookAheadCurriculum         wrapper, BPTT through n chained calls) and :216-223 (curriculum)
+  central_diff / darcy_loss     exp_darcy.py:59-68, 209-234 (decode, rel-L2 + 0.1 x derivative loss,
+  / darcy_train_step            clip, step) — the large-N single-call iteration
 """
 from __future__ import annotations
 
@@ -113,3 +117,79 @@ class GraphedRollout:
             self.graph.replay()
             frames.append(self.im.clone())
         return torch.cat(frames, -1)
+
+
+# ------------------------------------------------------------------------------ unrolled look-ahead training
+def unrolled_train_iteration(sol_model, x, fx, yy, look_ahead, step=1, loss_fn=None):
+    """One mini-batch of ns_vorticity_unrolling.py:225-244.  `sol_model.n` chained calls per window;
+    the window then advances by `look_ahead` GROUND-TRUTH frames.  Returns the loss (graph attached)."""
+    loss_fn = loss_fn or TestLoss(size_average=False)
+    sol_model.n = look_ahead
+    offset = step * look_ahead
+    T = yy.shape[-1]
+    bsz = x.shape[0]
+    loss = 0
+    for t in range(0, T - look_ahead + 1, look_ahead):
+        y = yy[..., t + offset - step:t + offset]
+        im = sol_model(x, fx)
+        loss = loss + loss_fn(im.reshape(bsz, -1), y.reshape(bsz, -1))
+        fx = torch.cat((fx[..., look_ahead:], yy[..., t:t + look_ahead]), dim=-1)
+    return loss
+
+
+class LookAheadCurriculum:
+    """look_ahead doubles (capped) whenever `ep % thresh == 0 and ep >= thresh`, after which the
+    threshold halves (ns_vorticity_unrolling.py:205-223)."""
+
+    def __init__(self, epochs, look_ahead=1, max_look_ahead=10):
+        self.look_ahead, self.max_look_ahead, self.thresh = look_ahead, max_look_ahead, epochs / 2
+
+    def update(self, ep):
+        if ep % self.thresh == 0 and ep >= self.thresh and self.look_ahead <= self.max_look_ahead:
+            self.look_ahead = min(self.look_ahead * 2, self.max_look_ahead)
+            self.thresh /= 2
+        return self.look_ahead
+
+
+# ------------------------------------------------------------------------------ Darcy iteration
+def central_diff(x, h, resolution):
+    """x: [B, res*res, C]; zero-padded central differences along image x / y (exp_darcy.py:59-68)."""
+    B, N, C = x.shape
+    img = torch.nn.functional.pad(x.reshape(B, resolution, resolution, C), (0, 0, 1, 1, 1, 1))
+    gx = (img[:, 1:-1, 2:, :] - img[:, 1:-1, :-2, :]) / (2 * h)
+    gy = (img[:, 2:, 1:-1, :] - img[:, :-2, 1:-1, :]) / (2 * h)
+    return gx, gy
+
+
+def darcy_loss(out, y, y_normalizer, dx, s, loss_fn=None):
+    """out, y: [B, N] normalised prediction / target.  Returns (loss, l2loss, deriv_loss) with
+    loss = l2 + 0.1 * (rel-L2 of d/dx + rel-L2 of d/dy), prediction border zeroed first."""
+    loss_fn = loss_fn or TestLoss(size_average=False)
+    out = y_normalizer.decode(out)
+    y = y_normalizer.decode(y)
+    l2 = loss_fn(out, y)
+    B = out.shape[0]
+    img = out.reshape(B, s, s)
+    inner = torch.zeros_like(img)
+    inner[:, 1:-1, 1:-1] = img[:, 1:-1, 1:-1]
+    gtx, gty = central_diff(y.unsqueeze(-1), dx, s)
+    px, py = central_diff(inner.reshape(B, s * s, 1), dx, s)
+    deriv = loss_fn(px, gtx) + loss_fn(py, gty)
+    return 0.1 * deriv + l2, l2, deriv
+
+
+def darcy_train_step(model, optimizer, scheduler, x, fx, y, y_normalizer, dx, s, max_grad_norm=None,
+                     grad_sync=None):
+    """exp_darcy.py:209-234: ONE model call per iteration (fun_dim = 1)."""
+    optimizer.zero_grad(set_to_none=False)
+    out = model(x, fx=fx.unsqueeze(-1)).squeeze(-1)
+    loss, l2, deriv = darcy_loss(out, y, y_normalizer, dx, s)
+    loss.backward()
+    if grad_sync is not None:
+        grad_sync()
+    if max_grad_norm is not None:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), max_grad_norm)
+    optimizer.step()
+    if scheduler is not None:
+        scheduler.step()
+    return loss.detach(), l2.detach(), deriv.detach()
