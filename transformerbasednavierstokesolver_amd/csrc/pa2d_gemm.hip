@@ -43,27 +43,6 @@ struct KCParams {
     unsigned c_bytes, res_bytes, aux_bytes;
 };
 
-// Raw buffer loads: lanes whose byte offset is >= num_records return 0 from the hardware range
-// check, so masked (padding / out-of-tile) elements need neither branches nor selects and the loads
-// stay asynchronous until the compiler's vmcnt wait in front of the LDS store.
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-#define OOB_OFF 0xFFFFFFFFu
-
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
-}
-__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff) {
-    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
-
-
-__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned voff) {
-    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
-}
-__device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned voff, float v) {
-    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, 0, 0);
-}
 __device__ __forceinline__ float gelu_f(float x) { return gelu_exact(x); }
 __device__ __forceinline__ float dgelu_f(float x) { return dgelu_exact(x); }
 

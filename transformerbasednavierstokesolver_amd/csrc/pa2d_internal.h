@@ -83,5 +83,37 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Raw buffer loads: lanes whose byte offset is >= num_records return 0 from the hardware range
+// check, so masked (padding / out-of-tile) elements need neither branches nor selects and the loads
+// stay asynchronous until the compiler's vmcnt wait in front of the LDS store.
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+#define OOB_OFF 0xFFFFFFFFu
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+    const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+
+
+__device__ __forceinline__ float buf_load1(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+    return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, voff, 0, 0));
+}
+__device__ __forceinline__ void buf_store1(__amdgpu_buffer_rsrc_t r, unsigned voff, float v) {
+    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), r, voff, 0, 0);
+}
+
+__device__ __forceinline__ float2 buf_load2(__amdgpu_buffer_rsrc_t r, unsigned voff) {
+    typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
+    const u32x2_ v = __builtin_amdgcn_raw_buffer_load_b64(r, voff, 0, 0);
+    return make_float2(__uint_as_float(v.x), __uint_as_float(v.y));
+}
+__device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned voff, float4 v) {
+    u32x4 u = {__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+    __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, 0, 0);
+}
+
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline long long ceil_div_ll(long long a, long long b) { return (a + b - 1) / b; }

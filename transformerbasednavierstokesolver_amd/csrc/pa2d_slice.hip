@@ -85,12 +85,29 @@ __device__ __forceinline__ void load_kfrag(const float* row, bool valid, int kq,
     }
 }
 
+// same fragment through a buffer descriptor: masked lanes (off == OOB_OFF) read 0, no branch
+template <int D>
+__device__ __forceinline__ void buf_kfrag(__amdgpu_buffer_rsrc_t r, unsigned off, int kq, float (&f)[SCfg<D>::KS]) {
+    constexpr int VEC = SCfg<D>::VEC, NV = SCfg<D>::NV;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+        if constexpr (VEC == 4) {
+            const float4 q = buf_load4(r, off == OOB_OFF ? OOB_OFF : off + (16 * v + 4 * kq) * 4u);
+            f[4 * v + 0] = q.x; f[4 * v + 1] = q.y; f[4 * v + 2] = q.z; f[4 * v + 3] = q.w;
+        } else {
+            const float2 q = buf_load2(r, off == OOB_OFF ? OOB_OFF : off + (8 * v + 2 * kq) * 4u);
+            f[2 * v + 0] = q.x; f[2 * v + 1] = q.y;
+        }
+    }
+}
+
 struct SliceParams {
     const float* xm; long long ldx;     // x_mid rows: xm[(b*N+n)*ldx + h*D + d]
     const float* v; long long ldv;      // values scattered (fx_mid forward, dY in backward phase A)
     const float* ws; const float* bs; const float* temperature;   // [M,D], [M], [heads]
     float* spart; float* npart;         // [B,heads,nchunk,M,D], [B,heads,nchunk,M] (npart may be null)
     int B, N, heads, M, nchunk, ppc;    // ppc = points per chunk (multiple of 16)
+    unsigned x_bytes, v_bytes;          // extents for the buffer descriptors
 };
 
 // S_partial[m][d] = sum_{n in chunk} W[n][m] * V[n][d];  n_partial[m] = sum_n W[n][m]
@@ -123,14 +140,29 @@ __global__ __launch_bounds__(256) void slice_scatter_kernel(const SliceParams p)
     }
     const int p_begin = chunk * p.ppc;
     const int p_end = min(p.N, p_begin + p.ppc);
-    const size_t row0 = (size_t)b * p.N;
-    for (int g = p_begin + wave * 16; g < p_end; g += 64) {
-        float xf[KS];
-        {
-            const int pt = g + li;
-            const bool pv = pt < p_end;
-            load_kfrag<D>(p.xm + (row0 + (pv ? pt : p_begin)) * p.ldx + hh * D, pv, kq, xf);
-        }
+    const unsigned row0 = (unsigned)b * (unsigned)p.N;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.xm, p.x_bytes);
+    const __amdgpu_buffer_rsrc_t rv = make_rsrc(p.v, p.v_bytes);
+    const unsigned ldx4 = (unsigned)p.ldx * 4u, ldv4 = (unsigned)p.ldv * 4u, hcol = (unsigned)(hh * D) * 4u;
+    // group loads: X as k-fragments (lane = point li), V as rows (lane = channel li) — branch-free
+    // buffer loads, issued one group ahead so that they fly under the 64 MFMAs of the current group
+#define SC_LOAD(g_, XF, FV)                                                                            \
+    {                                                                                                  \
+        const int pt_ = (g_) + li;                                                                     \
+        buf_kfrag<D>(rx, pt_ < p_end ? (row0 + pt_) * ldx4 + hcol : OOB_OFF, kq, XF);                   \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                \
+            const int pr_ = (g_) + 4 * kq + r;                                                         \
+            _Pragma("unroll") for (int dt = 0; dt < DT; ++dt) {                                        \
+                const int d_ = 16 * dt + li;                                                           \
+                FV[r][dt] = buf_load1(rv, (pr_ < p_end && d_ < D) ? (row0 + pr_) * ldv4 + hcol + d_ * 4u : OOB_OFF); \
+            }                                                                                          \
+        }                                                                                              \
+    }
+    float xf[KS], fv[4][DT], xf_n[KS], fv_n[4][DT];
+    int g = p_begin + wave * 16;
+    if (g < p_end) SC_LOAD(g, xf, fv)
+    for (; g < p_end; g += 64) {
+        if (g + 64 < p_end) SC_LOAD(g + 64, xf_n, fv_n)
         f32x4 w[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
@@ -165,17 +197,19 @@ __global__ __launch_bounds__(256) void slice_scatter_kernel(const SliceParams p)
             }
         }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int pr = g + 4 * kq + r;
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                const int d = 16 * dt + li;
-                const float fv = (pr < p_end && d < D) ? p.v[(row0 + pr) * p.ldv + hh * D + d] : 0.f;
+            for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) sacc[mt][dt] = mfma16(w[mt][r], fv, sacc[mt][dt]);
-            }
-        }
+                for (int mt = 0; mt < MT; ++mt) sacc[mt][dt] = mfma16(w[mt][r], fv[r][dt], sacc[mt][dt]);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xf[ks] = xf_n[ks];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) fv[r][dt] = fv_n[r][dt];
     }
+#undef SC_LOAD
     // deterministic cross-wave reduction: waves add in order 0,1,2,3
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) nacc[mt] = kq_sum(nacc[mt]);
@@ -207,6 +241,7 @@ struct DesliceParams {
     const float* ws; const float* bs; const float* temperature;
     float* y; long long ldy;            // y[(b*N+n)*ldy + h*D + d]
     int B, N, heads, M, nchunk, ppc;
+    unsigned x_bytes, y_bytes;
 };
 
 // Y[n][h*D+d] = sum_m W[n][m] * O[m][d]
@@ -238,12 +273,17 @@ __global__ __launch_bounds__(256) void deslice_kernel(const DesliceParams p) {
     }
     const int p_begin = chunk * p.ppc;
     const int p_end = min(p.N, p_begin + p.ppc);
-    const size_t row0 = (size_t)b * p.N;
-    for (int g = p_begin + wave * 16; g < p_end; g += 64) {
+    const unsigned row0 = (unsigned)b * (unsigned)p.N;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.xm, p.x_bytes);
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.y, p.y_bytes);
+    const unsigned ldx4 = (unsigned)p.ldx * 4u, ldy4 = (unsigned)p.ldy * 4u, hcol = (unsigned)(hh * D) * 4u;
+    float xf[KS], xf_n[KS];
+    int g = p_begin + wave * 16;
+    if (g < p_end) buf_kfrag<D>(rx, g + li < p_end ? (row0 + g + li) * ldx4 + hcol : OOB_OFF, kq, xf);
+    for (; g < p_end; g += 64) {
         const int pt = g + li;
         const bool pv = pt < p_end;
-        float xf[KS];
-        load_kfrag<D>(p.xm + (row0 + (pv ? pt : p_begin)) * p.ldx + hh * D, pv, kq, xf);
+        if (g + 64 < p_end) buf_kfrag<D>(rx, pt + 64 < p_end ? (row0 + pt + 64) * ldx4 + hcol : OOB_OFF, kq, xf_n);
         f32x4 w[MT];
         float mx = NEG_BIG;
 #pragma unroll
@@ -282,14 +322,14 @@ __global__ __launch_bounds__(256) void deslice_kernel(const DesliceParams p) {
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) yacc[dt] = mfma16(of[mt][r][dt], wv, yacc[dt]);
             }
-        if (pv) {
-            float* yr = p.y + (row0 + pt) * p.ldy + hh * D;
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                const int d = 16 * dt + 4 * kq;
-                if (d < D) *reinterpret_cast<float4*>(yr + d) = make_float4(yacc[dt][0], yacc[dt][1], yacc[dt][2], yacc[dt][3]);
-            }
+        for (int dt = 0; dt < DT; ++dt) {
+            const int d = 16 * dt + 4 * kq;
+            buf_store4(ry, (pv && d < D) ? (row0 + pt) * ldy4 + hcol + d * 4u : OOB_OFF,
+                       make_float4(yacc[dt][0], yacc[dt][1], yacc[dt][2], yacc[dt][3]));
         }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) xf[ks] = xf_n[ks];
     }
 }
 
@@ -303,6 +343,7 @@ struct SliceBwdParams {
     float* dfm; long long lddf;
     float* part;                        // per block: [M*D (dWs) | M (dbs) | 1 (dtau)]
     int B, N, heads, M, nchunk, ppc;
+    unsigned x_bytes, f_bytes, dy_bytes, dx_bytes, df_bytes;
 };
 
 // Backward phase C (per point): recompute W, then
@@ -360,15 +401,37 @@ __global__ __launch_bounds__(256) void slice_bwd_kernel(const SliceBwdParams p) 
     float* const myT = TL + wave * 16 * TP;
     const int p_begin = chunk * p.ppc;
     const int p_end = min(p.N, p_begin + p.ppc);
-    const size_t row0 = (size_t)b * p.N;
-    for (int g = p_begin + wave * 16; g < p_end; g += 64) {
+    const unsigned row0 = (unsigned)b * (unsigned)p.N;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.xm, p.x_bytes);
+    const __amdgpu_buffer_rsrc_t rf = make_rsrc(p.fm, p.f_bytes);
+    const __amdgpu_buffer_rsrc_t rg = make_rsrc(p.dy, p.dy_bytes);
+    const __amdgpu_buffer_rsrc_t rdx = make_rsrc(p.dxm, p.dx_bytes);
+    const __amdgpu_buffer_rsrc_t rdf = make_rsrc(p.dfm, p.df_bytes);
+    const unsigned ldx4 = (unsigned)p.ldx * 4u, ldf4 = (unsigned)p.ldf * 4u, ldg4 = (unsigned)p.lddy * 4u;
+    const unsigned lddx4 = (unsigned)p.lddx * 4u, lddf4 = (unsigned)p.lddf * 4u, hcol = (unsigned)(hh * D) * 4u;
+    // one-group-ahead prefetch of the three k-fragments and of the X rows used by dWs
+#define BW_LOAD(g_, XF, FF, GF, XV)                                                                    \
+    {                                                                                                  \
+        const int pt_ = (g_) + li;                                                                     \
+        const bool ok_ = pt_ < p_end;                                                                  \
+        buf_kfrag<D>(rx, ok_ ? (row0 + pt_) * ldx4 + hcol : OOB_OFF, kq, XF);                           \
+        buf_kfrag<D>(rf, ok_ ? (row0 + pt_) * ldf4 + hcol : OOB_OFF, kq, FF);                           \
+        buf_kfrag<D>(rg, ok_ ? (row0 + pt_) * ldg4 + hcol : OOB_OFF, kq, GF);                           \
+        _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                \
+            const int pr_ = (g_) + 4 * kq + r;                                                         \
+            _Pragma("unroll") for (int dt = 0; dt < DT; ++dt) {                                        \
+                const int d_ = 16 * dt + li;                                                           \
+                XV[r][dt] = buf_load1(rx, (pr_ < p_end && d_ < D) ? (row0 + pr_) * ldx4 + hcol + d_ * 4u : OOB_OFF); \
+            }                                                                                          \
+        }                                                                                              \
+    }
+    float xf[KS], ff[KS], gf[KS], xv[4][DT], xf_n[KS], ff_n[KS], gf_n[KS], xv_n[4][DT];
+    int g = p_begin + wave * 16;
+    if (g < p_end) BW_LOAD(g, xf, ff, gf, xv)
+    for (; g < p_end; g += 64) {
         const int pt = g + li;
         const bool pv = pt < p_end;
-        const size_t prow = row0 + (pv ? pt : p_begin);
-        float xf[KS], ff[KS], gf[KS];
-        load_kfrag<D>(p.xm + prow * p.ldx + hh * D, pv, kq, xf);
-        load_kfrag<D>(p.fm + prow * p.ldf + hh * D, pv, kq, ff);
-        load_kfrag<D>(p.dy + prow * p.lddy + hh * D, pv, kq, gf);
+        if (g + 64 < p_end) BW_LOAD(g + 64, xf_n, ff_n, gf_n, xv_n)
 
         // logits^T and dW^T (rows m = 16mt+4kq+r, cols pt = li)
         f32x4 w[MT], dw[MT];
@@ -467,18 +530,15 @@ __global__ __launch_bounds__(256) void slice_bwd_kernel(const SliceBwdParams p) 
                     xacc[dt] = mfma16(WsL[mrow + 16 * dt + li], dw[mt][r], xacc[dt]);
                 }
             }
-        if (pv) {
-            float* fr = p.dfm + (row0 + pt) * p.lddf + hh * D;
-            float* xr = p.dxm + (row0 + pt) * p.lddx + hh * D;
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                const int d = 16 * dt + 4 * kq;
-                if (d < D) {
-                    *reinterpret_cast<float4*>(fr + d) = make_float4(facc[dt][0], facc[dt][1], facc[dt][2], facc[dt][3]);
-                    *reinterpret_cast<float4*>(xr + d) = make_float4(xacc[dt][0] * inv_tau, xacc[dt][1] * inv_tau,
-                                                                     xacc[dt][2] * inv_tau, xacc[dt][3] * inv_tau);
-                }
-            }
+        for (int dt = 0; dt < DT; ++dt) {
+            const int d = 16 * dt + 4 * kq;
+            const bool ok = pv && d < D;
+            buf_store4(rdf, ok ? (row0 + pt) * lddf4 + hcol + d * 4u : OOB_OFF,
+                       make_float4(facc[dt][0], facc[dt][1], facc[dt][2], facc[dt][3]));
+            buf_store4(rdx, ok ? (row0 + pt) * lddx4 + hcol + d * 4u : OOB_OFF,
+                       make_float4(xacc[dt][0] * inv_tau, xacc[dt][1] * inv_tau, xacc[dt][2] * inv_tau,
+                                   xacc[dt][3] * inv_tau));
         }
         // dWs += dL^T . X : transpose the 16 x M tile of dL through wave-private LDS so that the
         // slice index lands on the lane (A operand i = m, k = point)
@@ -490,23 +550,23 @@ __global__ __launch_bounds__(256) void slice_bwd_kernel(const SliceBwdParams p) 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int pr = g + 4 * kq + r;
-            float xv[DT];
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                const int d = 16 * dt + li;
-                xv[dt] = (pr < p_end && d < D) ? p.xm[(row0 + pr) * p.ldx + hh * D + d] : 0.f;
-            }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const float a = myT[(4 * kq + r) * TP + 16 * mt + li];
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt) wsacc[mt][dt] = mfma16(a, xv[dt], wsacc[mt][dt]);
+                for (int dt = 0; dt < DT; ++dt) wsacc[mt][dt] = mfma16(a, xv[r][dt], wsacc[mt][dt]);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) { xf[ks] = xf_n[ks]; ff[ks] = ff_n[ks]; gf[ks] = gf_n[ks]; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) xv[r][dt] = xv_n[r][dt];
     }
+#undef BW_LOAD
 
     // block partials: dWs [M][D], dbs [M], dtau — waves add in fixed order
 #pragma unroll
@@ -632,6 +692,13 @@ int pa2d_slice_scatter(const float* xm, long long ldx, const float* v, long long
     p.spart = spart; p.npart = npart; p.B = B; p.N = N; p.heads = heads; p.M = M;
     p.nchunk = pa2d_slice_nchunk(B, N, heads);
     p.ppc = ppc_for(N, p.nchunk);
+    {
+        const unsigned long long rows = (unsigned long long)B * N;
+        const unsigned long long xb = ((rows - 1) * ldx + (unsigned long long)heads * D) * 4ull;
+        const unsigned long long vb = ((rows - 1) * ldv + (unsigned long long)heads * D) * 4ull;
+        if (xb >= 0xFFFFFFF0ull || vb >= 0xFFFFFFF0ull) return PA2D_ERR_UNSUPPORTED;
+        p.x_bytes = (unsigned)xb; p.v_bytes = (unsigned)vb;
+    }
     const int grid = B * heads * p.nchunk;
 #define CALL_SC(D_, MT_) launch_scatter_t<D_, MT_>(p, grid, st)
     DISPATCH_D(CALL_SC)
@@ -649,6 +716,13 @@ int pa2d_deslice_fwd(const float* xm, long long ldx, const float* o, const float
     p.B = B; p.N = N; p.heads = heads; p.M = M;
     p.nchunk = pa2d_slice_nchunk(B, N, heads);
     p.ppc = ppc_for(N, p.nchunk);
+    {
+        const unsigned long long rows = (unsigned long long)B * N;
+        const unsigned long long xb = ((rows - 1) * ldx + (unsigned long long)heads * D) * 4ull;
+        const unsigned long long yb = ((rows - 1) * ldy + (unsigned long long)heads * D) * 4ull;
+        if (xb >= 0xFFFFFFF0ull || yb >= 0xFFFFFFF0ull) return PA2D_ERR_UNSUPPORTED;
+        p.x_bytes = (unsigned)xb; p.y_bytes = (unsigned)yb;
+    }
     const int grid = B * heads * p.nchunk;
 #define CALL_DS(D_, MT_) launch_deslice_t<D_, MT_>(p, grid, st)
     DISPATCH_D(CALL_DS)
@@ -676,6 +750,16 @@ int pa2d_slice_bwd_points(const float* xm, long long ldx, const float* fm, long 
     p.lddf = lddf; p.part = (float*)ws_buf; p.B = B; p.N = N; p.heads = heads; p.M = M;
     p.nchunk = pa2d_slice_nchunk(B, N, heads);
     p.ppc = ppc_for(N, p.nchunk);
+    {
+        const unsigned long long rows = (unsigned long long)B * N, w = (unsigned long long)heads * D;
+        const unsigned long long e[5] = {((rows - 1) * ldx + w) * 4ull, ((rows - 1) * ldf + w) * 4ull,
+                                         ((rows - 1) * lddy + w) * 4ull, ((rows - 1) * lddx + w) * 4ull,
+                                         ((rows - 1) * lddf + w) * 4ull};
+        for (int i = 0; i < 5; ++i)
+            if (e[i] >= 0xFFFFFFF0ull) return PA2D_ERR_UNSUPPORTED;
+        p.x_bytes = (unsigned)e[0]; p.f_bytes = (unsigned)e[1]; p.dy_bytes = (unsigned)e[2];
+        p.dx_bytes = (unsigned)e[3]; p.df_bytes = (unsigned)e[4];
+    }
     const int grid = B * heads * p.nchunk;
     int rc = PA2D_OK;
 #define CALL_BW(D_, MT_) rc = launch_bwd_t<D_, MT_>(p, grid, st)
