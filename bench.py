@@ -107,7 +107,11 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rollout", action="store_true")
+    ap.add_argument("--gemm-mode", type=int, default=0,
+                    help="0 = exact fp32 MFMA (the metric of record), 2 = bf16-compute mode (BASELINE configs[2] numerics)")
     args = ap.parse_args()
+    from transformerbasednavierstokesolver_amd import _lib
+    _lib.load().pa2d_set_gemm_mode(args.gemm_mode)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -202,7 +206,7 @@ def main():
     out = {
         "metric": "ns64_train_samples_per_s", "value": round(world * B * args.steps / dt, 4), "unit": "samples/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.gemm_mode == 0 else ("f32 via 6-term bf16 split (conv)" if args.gemm_mode == 1 else "bf16 MFMA compute, f32 accumulate+storage"), "data": "synthetic",
         "config": {"workload": "exp_ns.py training iteration on NS 64x64 (10 teacher-forced Transolver calls + "
                                "backward + AdamW/OneCycleLR): Transolver_Structured_Mesh_2D 8 layers, C=256, 8 heads, "
                                "M=64 slices, fp32, batch 32/GPU (BASELINE configs[1])",

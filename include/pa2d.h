@@ -37,7 +37,10 @@ const char* pa2d_version(void);
 /* Process-wide engine selection for the conv implicit GEMMs (also env PA2D_GEMM=f32|split at first use):
  * 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), the default and what bench.py measures;
  * 1 = experimental: operands split into 3 bf16 terms, 6 bf16 MFMA terms per product, fp32 accumulate
- *     (fp32-level accuracy, same parity tolerances). */
+ *     (fp32-level accuracy, same parity tolerances);
+ * 2 = bf16 compute (env PA2D_GEMM=bf16): every GEMM (conv, linears, weight gradients) rounds its
+ *     operands to bf16 while staging and uses ONE bf16 MFMA term with fp32 accumulation; tensors stay
+ *     fp32 in HBM.  Autocast-style numerics for BASELINE configs[2]/[4] (tolerance rel-L2 <= 3e-2). */
 void pa2d_set_gemm_mode(int mode);
 int pa2d_get_gemm_mode(void);
 

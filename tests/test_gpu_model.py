@@ -237,3 +237,24 @@ def test_darcy_iteration_matches_oracle():
     for k, p in m.named_parameters():
         if k != "placeholder":
             assert rel_l2(p.grad, sdo[k].grad) < _grad_tol(k), k
+
+
+def test_bf16_compute_mode_full_ns_model():
+    """BASELINE configs[2] numerics: the full NS model (8 layers, C=256) with every GEMM in bf16-compute
+    mode against the fp64 reference output; SURVEY 8c tolerance for bf16 forward: rel-L2 <= 3e-2."""
+    from transformerbasednavierstokesolver_amd import synth, harness, _lib
+    g = np.load(os.path.join(GOLDEN, "G5_full_ns.npz"))
+    cfg = synth.NS_CONFIG
+    m = harness.build_model(cfg, synth.synth_state_dict(cfg, seed=51), DEV)
+    pos, a, u = synth.ns_batch(1, seed=52)
+    x, fx = torch.from_numpy(pos).to(DEV), torch.from_numpy(a).to(DEV)
+    lib = _lib.load()
+    lib.pa2d_set_gemm_mode(2)
+    try:
+        pred = m(x, fx=fx)
+        pred.square().sum().backward()
+        e = rel_l2(pred.reshape(-1), g["pred"])
+    finally:
+        lib.pa2d_set_gemm_mode(0)
+    assert 1e-5 < e < 3e-2, e          # really ran in reduced precision, and within the bf16 tolerance
+    assert all(torch.isfinite(p.grad).all() for k, p in m.named_parameters() if p.grad is not None)

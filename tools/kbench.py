@@ -31,7 +31,10 @@ def main():
     ap.add_argument("--B", type=int, default=32)
     ap.add_argument("--C", type=int, default=256)
     ap.add_argument("--M", type=int, default=64)
+    ap.add_argument("--gemm-mode", type=int, default=0, help="0 f32 MFMA, 1 6-term bf16 split (conv), 2 bf16 compute")
     args = ap.parse_args()
+    from transformerbasednavierstokesolver_amd import _lib
+    _lib.load().pa2d_set_gemm_mode(args.gemm_mode)
     only = set(filter(None, args.only.split(",")))
     dev = "cuda:0"
     B, H, W, C, heads, M = args.B, 64, 64, args.C, 8, args.M

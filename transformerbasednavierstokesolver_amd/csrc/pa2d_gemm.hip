@@ -263,9 +263,11 @@ __device__ __forceinline__ void split3(const float4 v, bf16x4& hi, bf16x4& mid, 
 //                          (k+1)&1, then put the loads of K-step k+2 in flight;
 //   waves 0-3 (consumers): 48 MFMAs per K-step on stage k&1 (2x2 tiles of 32x32, 2 k-halves, 6 terms).
 // One __syncthreads per K-step hands stage (k+1)&1 over and frees stage k&1.
-template <int BM, int BN, bool IM2COL>
+// NT = 3: the 6-term fp32-accuracy split above.  NT = 1: plain bf16 compute (operands rounded to bf16,
+// ONE MFMA term, fp32 accumulate) — the autocast-style numerics of BASELINE configs[2]/[4].
+template <int BM, int BN, bool IM2COL, int NT>
 __global__ __launch_bounds__(512, 2) void gemm_kc_split_kernel(const KCParams p) {
-    constexpr int BK = 32, PITCHB = 208;                 // bytes per LDS row (3 planes x 64 B + 16)
+    constexpr int BK = 32, PITCHB = NT * 64 + 16;        // bytes per LDS row (NT planes x 64 B + 16): 208 / 80
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int A_IT = BM / 32, B_IT = BN / 32;        // float4 per producer thread per K-step
     constexpr int STAGE = (BM + BN) * PITCHB;
@@ -336,16 +338,20 @@ __global__ __launch_bounds__(512, 2) void gemm_kc_split_kernel(const KCParams p)
             split3(ra[s], h_, m_, l_);                                                                 \
             unsigned char* d_ = As_ + (lr + 32 * s) * PITCHB + lq * 8;                                 \
             *reinterpret_cast<bf16x4*>(d_) = h_;                                                       \
-            *reinterpret_cast<bf16x4*>(d_ + 64) = m_;                                                  \
-            *reinterpret_cast<bf16x4*>(d_ + 128) = l_;                                                 \
+            if (NT == 3) {                                                                             \
+                *reinterpret_cast<bf16x4*>(d_ + 64) = m_;                                              \
+                *reinterpret_cast<bf16x4*>(d_ + 128) = l_;                                             \
+            }                                                                                          \
         }                                                                                              \
         _Pragma("unroll") for (int s = 0; s < B_IT; ++s) {                                             \
             bf16x4 h_, m_, l_;                                                                         \
             split3(rb[s], h_, m_, l_);                                                                 \
             unsigned char* d_ = Bs_ + (lr + 32 * s) * PITCHB + lq * 8;                                 \
             *reinterpret_cast<bf16x4*>(d_) = h_;                                                       \
-            *reinterpret_cast<bf16x4*>(d_ + 64) = m_;                                                  \
-            *reinterpret_cast<bf16x4*>(d_ + 128) = l_;                                                 \
+            if (NT == 3) {                                                                             \
+                *reinterpret_cast<bf16x4*>(d_ + 64) = m_;                                              \
+                *reinterpret_cast<bf16x4*>(d_ + 128) = l_;                                             \
+            }                                                                                          \
         }                                                                                              \
     }
         KS_LOAD(0)
@@ -380,27 +386,28 @@ __global__ __launch_bounds__(512, 2) void gemm_kc_split_kernel(const KCParams p)
         const unsigned char* b_s = smem + (kc & 1) * STAGE + BM * PITCHB + wn * WN * PITCHB + frag_off;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[TM][3], bf[TN][3];
+            bf16x8 af[TM][NT], bf[TN][NT];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int q = 0; q < 3; ++q)
+                for (int q = 0; q < NT; ++q)
                     af[i][q] = *reinterpret_cast<const bf16x8*>(a_s + i * 32 * PITCHB + q * 64 + ks * 32);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int q = 0; q < 3; ++q)
+                for (int q = 0; q < NT; ++q)
                     bf[j][q] = *reinterpret_cast<const bf16x8*>(b_s + j * 32 * PITCHB + q * 64 + ks * 32);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    // smallest terms first
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                    if constexpr (NT == 3) {   // smallest terms first
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                    }
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
                 }
         }
@@ -410,19 +417,26 @@ __global__ __launch_bounds__(512, 2) void gemm_kc_split_kernel(const KCParams p)
     kc_epilogue<TM, TN>(p, acc, tile_m * BM + wm * WM + 4 * (lane >> 5), tile_n * BN + wn * WN + (lane & 31));
 }
 
-// engine selection: PA2D_GEMM=f32 (v_mfma_f32_32x32x2_f32) or split (6-term bf16 split, fp32 accuracy)
-static int g_gemm_mode = -1;   // process-wide tuning knob (pa2d_set_gemm_mode / env PA2D_GEMM), default f32
-static int gemm_mode_split() {
+// engine selection: PA2D_GEMM=f32 (v_mfma_f32_32x32x2_f32, default) | split (6-term bf16 split, fp32
+// accuracy, conv GEMMs only) | bf16 (1-term bf16 compute for every GEMM, fp32 accumulate/storage)
+static int g_gemm_mode = -1;   // process-wide knob (pa2d_set_gemm_mode / env PA2D_GEMM)
+static int gemm_mode() {
     if (g_gemm_mode < 0) {
         const char* e = getenv("PA2D_GEMM");
-        g_gemm_mode = (e && e[0] == 's') ? 1 : 0;
+        g_gemm_mode = !e ? 0 : (e[0] == 's' ? 1 : (e[0] == 'b' ? 2 : 0));
     }
     return g_gemm_mode;
 }
+static int gemm_mode_split() { return gemm_mode() != 0; }
 // chunk (channels per tap step) the conv weight packs must use for the selected engine
 // the experimental split engine is only used for the conv implicit GEMMs (it is slower than the f32
 // engine on the short-K linears)
-static bool use_split(int N, bool im2col, int Cin) { return gemm_mode_split() && im2col && N > 64 && (Cin % 32) == 0; }
+static bool use_split(int N, bool im2col, int Cin) {
+    const int m = gemm_mode();
+    if (m == 1) return im2col && N > 64 && (Cin % 32) == 0;
+    if (m == 2) return N > 64 && (!im2col || (Cin % 32) == 0);
+    return false;
+}
 static int conv_chunk(int Cin, int N) { return use_split(N, true, Cin) ? 32 : 16; }
 
 static int launch_kc(const KCParams& p_in, bool im2col, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
@@ -447,18 +461,25 @@ static int launch_kc(const KCParams& p_in, bool im2col, hipStream_t st, hipEvent
     if (use_split(p.N, im2col, p.Cin)) {
         const int tiles_n = ceil_div(p.N, 128);
         const dim3 grid(ceil_div(tiles_m, 8) * 8 * tiles_n);
-        const int smem = 2 * (128 + 128) * 208;
+        const bool bf = gemm_mode() == 2;
+        const int smem = 2 * (128 + 128) * (bf ? 80 : 208);
         static bool attr_done = false;
         if (!attr_done) {
-            hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kc_split_kernel<128, 128, true>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kc_split_kernel<128, 128, false>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            const int big = 2 * (128 + 128) * 208;
+            hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kc_split_kernel<128, 128, true, 3>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kc_split_kernel<128, 128, false, 3>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, big);
             if (e1 != hipSuccess || e2 != hipSuccess) return (int)(e1 != hipSuccess ? e1 : e2);
             attr_done = true;
         }
-        if (im2col) hipLaunchKernelGGL((gemm_kc_split_kernel<128, 128, true>), grid, dim3(512), smem, st, p);
-        else hipLaunchKernelGGL((gemm_kc_split_kernel<128, 128, false>), grid, dim3(512), smem, st, p);
+        if (bf) {
+            if (im2col) hipLaunchKernelGGL((gemm_kc_split_kernel<128, 128, true, 1>), grid, dim3(512), smem, st, p);
+            else hipLaunchKernelGGL((gemm_kc_split_kernel<128, 128, false, 1>), grid, dim3(512), smem, st, p);
+        } else {
+            if (im2col) hipLaunchKernelGGL((gemm_kc_split_kernel<128, 128, true, 3>), grid, dim3(512), smem, st, p);
+            else hipLaunchKernelGGL((gemm_kc_split_kernel<128, 128, false, 3>), grid, dim3(512), smem, st, p);
+        }
     } else {
         // tile choice: 128x128 when that already gives >= 1.5 workgroups per CU, otherwise smaller tiles
         // so that small problems (rollout at batch 1: M = 4096) still fill the 256 CUs
@@ -496,7 +517,10 @@ struct MCParams {
     unsigned a_bytes, b_bytes;
 };
 
-template <int BM, int BN, bool IM2COL>
+// BF16 = true: same staging (fp32 tiles [16 rows m][BM]), but each lane gathers its 8 consecutive m of
+// one column with 8 ds_read_b32, rounds them to bf16 and issues ONE v_mfma_f32_32x32x16_bf16 per tile
+// and 16-row chunk instead of 8 fp32 MFMAs (bf16-compute mode).
+template <int BM, int BN, bool IM2COL, bool BF16>
 __global__ __launch_bounds__(256, 2) void gemm_mc_kernel(const MCParams p) {
     constexpr int BK = 16;
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
@@ -600,6 +624,24 @@ __global__ __launch_bounds__(256, 2) void gemm_mc_kernel(const MCParams p) {
         if (c + 1 < c_end) MC_LOAD(c + 1)
         const float* a_s = As + buf * BK * BM + kh * BM + wm * WM + li;
         const float* b_s = Bs + buf * BK * BN + kh * BN + wn * WN + li;
+        if constexpr (BF16) {
+            const float* a8 = As + buf * BK * BM + kh * 8 * BM + wm * WM + li;
+            const float* b8 = Bs + buf * BK * BN + kh * 8 * BN + wn * WN + li;
+            bf16x8 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) af[i][e] = (__bf16)a8[e * BM + i * 32];
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) bf[j][e] = (__bf16)b8[e * BN + j * 32];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        } else {
         // fragments of k-step kk+1 are fetched into the other register set before the MFMAs of
         // k-step kk issue, so the LDS latency hides behind 4 x 64 MFMA cycles
         float af[2][TM], bf[2][TN];
@@ -629,6 +671,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mc_kernel(const MCParams p) {
             __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
         }
         __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+        }
         if (c + 1 < c_end) MC_STORE(buf ^ 1)
         __syncthreads();
     }
@@ -741,12 +784,16 @@ static int launch_mc(const float* A, long long lda, int Mi, const float* B, long
     }
     const int bm = pl.big ? 128 : 64;
     const dim3 grid(ceil_div(Mi, bm) * ceil_div(Nj, bm) * pl.splits);
-    if (pl.big) {
-        if (im2col) hipLaunchKernelGGL((gemm_mc_kernel<128, 128, true>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((gemm_mc_kernel<128, 128, false>), grid, dim3(256), 0, st, p);
+    const bool bf = gemm_mode() == 2;
+    if (pl.big && bf) {
+        if (im2col) hipLaunchKernelGGL((gemm_mc_kernel<128, 128, true, true>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_mc_kernel<128, 128, false, true>), grid, dim3(256), 0, st, p);
+    } else if (pl.big) {
+        if (im2col) hipLaunchKernelGGL((gemm_mc_kernel<128, 128, true, false>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_mc_kernel<128, 128, false, false>), grid, dim3(256), 0, st, p);
     } else {
-        if (im2col) hipLaunchKernelGGL((gemm_mc_kernel<64, 64, true>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((gemm_mc_kernel<64, 64, false>), grid, dim3(256), 0, st, p);
+        if (im2col) hipLaunchKernelGGL((gemm_mc_kernel<64, 64, true, false>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_mc_kernel<64, 64, false, false>), grid, dim3(256), 0, st, p);
     }
     PA2D_CHECK_LAUNCH();
     return PA2D_OK;
@@ -844,8 +891,8 @@ static int launch_repack(const float* w0, const float* w1, float* dst, int mode,
 extern "C" {
 
 // 0 = exact fp32 MFMA engine (default), 1 = experimental 6-term bf16-split engine for the conv GEMMs
-void pa2d_set_gemm_mode(int mode) { g_gemm_mode = mode ? 1 : 0; }
-int pa2d_get_gemm_mode(void) { return gemm_mode_split(); }
+void pa2d_set_gemm_mode(int mode) { g_gemm_mode = (mode == 1 || mode == 2) ? mode : 0; }
+int pa2d_get_gemm_mode(void) { return gemm_mode(); }
 
 int pa2d_gemm_bias_act_fwd(const float* x, long long ldx, const float* w, long long ldw, const float* bias,
                            const float* res, long long ldres, float* y, long long ldy, float* pre, long long ldpre,
