@@ -10,7 +10,8 @@
  * Conventions
  *   - all tensors fp32, row-major, device pointers; "ld*" = row pitch in floats;
  *   - the caller owns every buffer (outputs and workspaces); nothing here allocates, frees or
- *     synchronises, there is no static state -> safe under hipGraph capture and on any stream;
+ *     synchronises; the only process-wide state is the engine selector pa2d_set_gemm_mode -> safe
+ *     under hipGraph capture and on any stream;
  *   - hipStream_t is passed as void* (torch.cuda.current_stream().cuda_stream);
  *   - return value: 0 = ok, otherwise a hipError_t or PA2D_ERR_* (never a silent fallback);
  *   - activation ids follow the reference's ACTIVATION table (…_2D.py:9-10).
