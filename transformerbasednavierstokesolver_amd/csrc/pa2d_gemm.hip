@@ -289,7 +289,12 @@ __global__ __launch_bounds__(512, 2) void gemm_kc_split_kernel(const KCParams p)
         const int lr = ptid >> 3, lq = ptid & 7;         // 8 lanes cover one 128-byte row segment
         const __amdgpu_buffer_rsrc_t ra_rsrc = make_rsrc(p.A, p.a_bytes);
         const __amdgpu_buffer_rsrc_t rb_rsrc = make_rsrc(p.B, p.b_bytes);
-        unsigned a_off[A_IT], b_off[B_IT];
+        // The conv weights arrive PRE-SPLIT from the pack kernel as the exact LDS row image
+        // ([n][K-step][plane][32] bf16): the B tile is then copied with 16-byte pieces, no VALU.
+        constexpr bool PRESPLIT = IM2COL;
+        constexpr int PIECES = NT * 4;                            // 16-byte pieces per row and K-step
+        constexpr int BP_IT = (BN * PIECES) / 256;                // pieces per producer thread
+        unsigned a_off[A_IT], b_off[B_IT], bp_off[BP_IT], bp_lds[BP_IT];
         int a_y[A_IT], a_x[A_IT];
 #pragma unroll
         for (int s = 0; s < A_IT; ++s) {
@@ -308,8 +313,17 @@ __global__ __launch_bounds__(512, 2) void gemm_kc_split_kernel(const KCParams p)
             const int gn = tile_n * BN + lr + 32 * s;
             b_off[s] = gn < p.N ? (unsigned)gn * (unsigned)p.ldb * 4u + lq * 16u : OOB_OFF;
         }
-        float4 ra[A_IT], rb[B_IT];
-#define KS_LOAD(kc_)                                                                                   \
+#pragma unroll
+        for (int s = 0; s < BP_IT; ++s) {
+            const int q = ptid + 256 * s, row = q / PIECES, piece = q - row * PIECES;
+            const int gn = tile_n * BN + row;
+            bp_off[s] = gn < p.N ? ((unsigned)gn * (unsigned)nk * PIECES + piece) * 16u : OOB_OFF;
+            bp_lds[s] = row * PITCHB + piece * 16;
+        }
+        // two register sets: K-step c lives in set c&1 and is loaded two barriers before it is stored
+        float4 ra0[A_IT], ra1[A_IT], rb0[B_IT], rb1[B_IT];
+        u32x4 rp0[BP_IT], rp1[BP_IT];
+#define KS_LOAD(kc_, RA, RB, RP)                                                                       \
     {                                                                                                  \
         const int k0_ = (kc_) * BK;                                                                    \
         const bool kin_ = k0_ + lq * 4 < p.K;                                                          \
@@ -320,22 +334,28 @@ __global__ __launch_bounds__(512, 2) void gemm_kc_split_kernel(const KCParams p)
             _Pragma("unroll") for (int s = 0; s < A_IT; ++s) {                                         \
                 const bool ok_ = (unsigned)(a_y[s] + dy_) < (unsigned)p.H &&                           \
                                  (unsigned)(a_x[s] + dx_) < (unsigned)p.W && a_off[s] != OOB_OFF;      \
-                ra[s] = buf_load4(ra_rsrc, ok_ ? a_off[s] + (unsigned)sh_ : OOB_OFF);                  \
+                RA[s] = buf_load4(ra_rsrc, ok_ ? a_off[s] + (unsigned)sh_ : OOB_OFF);                  \
             }                                                                                          \
         } else {                                                                                       \
             _Pragma("unroll") for (int s = 0; s < A_IT; ++s)                                           \
-                ra[s] = buf_load4(ra_rsrc, (kin_ && a_off[s] != OOB_OFF) ? a_off[s] + k0_ * 4u : OOB_OFF); \
+                RA[s] = buf_load4(ra_rsrc, (kin_ && a_off[s] != OOB_OFF) ? a_off[s] + k0_ * 4u : OOB_OFF); \
         }                                                                                              \
-        _Pragma("unroll") for (int s = 0; s < B_IT; ++s)                                               \
-            rb[s] = buf_load4(rb_rsrc, (kin_ && b_off[s] != OOB_OFF) ? b_off[s] + k0_ * 4u : OOB_OFF); \
+        if (PRESPLIT) {                                                                                \
+            _Pragma("unroll") for (int s = 0; s < BP_IT; ++s)                                          \
+                RP[s] = __builtin_amdgcn_raw_buffer_load_b128(                                         \
+                    rb_rsrc, bp_off[s] != OOB_OFF ? bp_off[s] + (unsigned)(kc_) * (PIECES * 16u) : OOB_OFF, 0, 0); \
+        } else {                                                                                       \
+            _Pragma("unroll") for (int s = 0; s < B_IT; ++s)                                           \
+                RB[s] = buf_load4(rb_rsrc, (kin_ && b_off[s] != OOB_OFF) ? b_off[s] + k0_ * 4u : OOB_OFF); \
+        }                                                                                              \
     }
-#define KS_STORE(buf_)                                                                                 \
+#define KS_STORE(buf_, RA, RB, RP)                                                                     \
     {                                                                                                  \
         unsigned char* const As_ = smem + (buf_) * STAGE;                                              \
         unsigned char* const Bs_ = As_ + BM * PITCHB;                                                  \
         _Pragma("unroll") for (int s = 0; s < A_IT; ++s) {                                             \
             bf16x4 h_, m_, l_;                                                                         \
-            split3(ra[s], h_, m_, l_);                                                                 \
+            split3(RA[s], h_, m_, l_);                                                                 \
             unsigned char* d_ = As_ + (lr + 32 * s) * PITCHB + lq * 8;                                 \
             *reinterpret_cast<bf16x4*>(d_) = h_;                                                       \
             if (NT == 3) {                                                                             \
@@ -343,27 +363,40 @@ __global__ __launch_bounds__(512, 2) void gemm_kc_split_kernel(const KCParams p)
                 *reinterpret_cast<bf16x4*>(d_ + 128) = l_;                                             \
             }                                                                                          \
         }                                                                                              \
-        _Pragma("unroll") for (int s = 0; s < B_IT; ++s) {                                             \
-            bf16x4 h_, m_, l_;                                                                         \
-            split3(rb[s], h_, m_, l_);                                                                 \
-            unsigned char* d_ = Bs_ + (lr + 32 * s) * PITCHB + lq * 8;                                 \
-            *reinterpret_cast<bf16x4*>(d_) = h_;                                                       \
-            if (NT == 3) {                                                                             \
-                *reinterpret_cast<bf16x4*>(d_ + 64) = m_;                                              \
-                *reinterpret_cast<bf16x4*>(d_ + 128) = l_;                                             \
+        if (PRESPLIT) {                                                                                \
+            _Pragma("unroll") for (int s = 0; s < BP_IT; ++s)                                          \
+                *reinterpret_cast<u32x4*>(Bs_ + bp_lds[s]) = RP[s];                                    \
+        } else {                                                                                       \
+            _Pragma("unroll") for (int s = 0; s < B_IT; ++s) {                                         \
+                bf16x4 h_, m_, l_;                                                                     \
+                split3(RB[s], h_, m_, l_);                                                             \
+                unsigned char* d_ = Bs_ + (lr + 32 * s) * PITCHB + lq * 8;                             \
+                *reinterpret_cast<bf16x4*>(d_) = h_;                                                   \
+                if (NT == 3) {                                                                         \
+                    *reinterpret_cast<bf16x4*>(d_ + 64) = m_;                                          \
+                    *reinterpret_cast<bf16x4*>(d_ + 128) = l_;                                         \
+                }                                                                                      \
             }                                                                                          \
         }                                                                                              \
     }
-        KS_LOAD(0)
-        KS_STORE(0)
-        if (nk > 1) KS_LOAD(1)
+        KS_LOAD(0, ra0, rb0, rp0)
+        if (nk > 1) KS_LOAD(1, ra1, rb1, rp1)
+        KS_STORE(0, ra0, rb0, rp0)
+        if (nk > 2) KS_LOAD(2, ra0, rb0, rp0)
         __syncthreads();
-        for (int kc = 0; kc < nk; ++kc) {
-            if (kc + 1 < nk) {
-                KS_STORE((kc + 1) & 1)
-                if (kc + 2 < nk) KS_LOAD(kc + 2)
+        for (int kc = 0; kc < nk; kc += 2) {
+            if (kc + 1 < nk) {                               // K-step kc+1 lives in set 1
+                KS_STORE((kc + 1) & 1, ra1, rb1, rp1)
+                if (kc + 3 < nk) KS_LOAD(kc + 3, ra1, rb1, rp1)
             }
             __syncthreads();
+            if (kc + 1 < nk) {
+                if (kc + 2 < nk) {                           // K-step kc+2 lives in set 0
+                    KS_STORE((kc + 2) & 1, ra0, rb0, rp0)
+                    if (kc + 4 < nk) KS_LOAD(kc + 4, ra0, rb0, rp0)
+                }
+                __syncthreads();
+            }
         }
 #undef KS_LOAD
 #undef KS_STORE
@@ -371,6 +404,11 @@ __global__ __launch_bounds__(512, 2) void gemm_kc_split_kernel(const KCParams p)
     }
 
     // ---------------- consumers
+    // Ablation of the 6-term conv launch (2.1 ms): MFMAs skipped 1.16 ms, global loads skipped 1.48,
+    // convert+LDS store skipped 1.56, both skipped 1.24 (= consumers alone; MFMA floor 0.84), loads alone
+    // 0.73 (40 KB per K-step = 32 B/clk/CU, the CU's load-path limit), convert+store alone 0.78.  With one
+    // workgroup per CU the staging phases do not hide behind the MFMAs; static MFMA-wave priority
+    // (s_setprio) made no difference.  Next step: a tiling that converts each A tile once, not 4 times.
     const int wm = wave >> 1, wn = wave & 1;
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -459,6 +497,7 @@ static int launch_kc(const KCParams& p_in, bool im2col, hipStream_t st, hipEvent
     const int tiles_m = ceil_div(p.M, 128);
     if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return PA2D_ERR_ARG;
     if (use_split(p.N, im2col, p.Cin)) {
+        if (im2col) p.b_bytes = (unsigned)((size_t)p.N * (p.K / 32) * (gemm_mode() == 2 ? 1 : 3) * 64);
         const int tiles_n = ceil_div(p.N, 128);
         const dim3 grid(ceil_div(tiles_m, 8) * 8 * tiles_n);
         const bool bf = gemm_mode() == 2;
@@ -877,6 +916,45 @@ __global__ void repack_kernel(const float* __restrict__ w0, const float* __restr
     }
 }
 
+// conv weight pack for the bf16 engines: dst row n = [K-step kc = cic*9+tap][plane][32 channels] bf16,
+// i.e. the LDS row image of gemm_kc_split_kernel (NT planes: hi | mid | lo).  bwd != 0: data-gradient
+// layout (rows = input channels, contraction over the 2C output channels, taps mirrored).
+__global__ void repack_split_kernel(const float* __restrict__ w0, const float* __restrict__ w1,
+                                    __bf16* __restrict__ dst, int bwd, int NT, int C, int Cin) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)2 * C * 9 * Cin) return;
+    float v;
+    int n, kc, c32;
+    if (!bwd) {          // rows n = output channel co' in [0,2C), K = 9*Cin
+        c32 = (int)(idx % 32);
+        const int tap = (int)((idx / 32) % 9);
+        const int cic = (int)((idx / 288) % (Cin / 32));
+        n = (int)(idx / ((long long)Cin * 9));
+        kc = cic * 9 + tap;
+        const float* src = n < C ? w0 : w1;
+        v = src[((size_t)(n % C) * Cin + cic * 32 + c32) * 9 + tap];
+    } else {             // rows n = input channel ci in [0,Cin), K = 9*2C
+        c32 = (int)(idx % 32);
+        const int tap = (int)((idx / 32) % 9);
+        const int cic = (int)((idx / 288) % (2 * C / 32));
+        n = (int)(idx / ((long long)2 * C * 9));
+        kc = cic * 9 + tap;
+        const int co = cic * 32 + c32;
+        const float* src = co < C ? w0 : w1;
+        v = src[((size_t)(co % C) * Cin + n) * 9 + (8 - tap)];
+    }
+    const int nk = bwd ? (2 * C / 32) * 9 : (Cin / 32) * 9;
+    __bf16* d = dst + ((size_t)n * nk + kc) * NT * 32 + c32;
+    const __bf16 h = (__bf16)v;
+    d[0] = h;
+    if (NT == 3) {
+        const float r1 = v - (float)h;
+        const __bf16 m = (__bf16)r1;
+        d[32] = m;
+        d[64] = (__bf16)(r1 - (float)m);
+    }
+}
+
 static int launch_repack(const float* w0, const float* w1, float* dst, int mode, int N, int K, int C, int Cin,
                          hipStream_t st) {
     const long long count = mode == 0 ? (long long)N * K : (long long)2 * C * 9 * Cin;
@@ -940,7 +1018,7 @@ int pa2d_gemm_bwd_weight(const float* dy, long long lddy, const float* x, long l
 }
 
 size_t pa2d_conv3x3x2_workspace(int B, int H, int W, int C) {
-    const size_t pack = (size_t)2 * C * 9 * C;
+    const size_t pack = (size_t)3 * C * 9 * C;      // fp32 pack (2C*9C floats) or 3 bf16 planes (1.5x)
     const MCPlan pl = plan_mc(2 * C, 9 * C, B * H * W);
     size_t sl = pl.slab_floats, cs = (size_t)colsum_blocks(B * H * W) * 2 * C;
     return (pack + (sl > cs ? sl : cs)) * sizeof(float);
@@ -952,10 +1030,18 @@ size_t pa2d_conv3x3x2_workspace(int B, int H, int W, int C) {
 int pa2d_conv3x3x2_fwd(const float* xn, const float* wx, const float* bx, const float* wf, const float* bf,
                        float* out, float* bias2_ws /* 2C floats */, void* ws, size_t ws_bytes, int B, int H, int W,
                        int C, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
-    if (ws_bytes < (size_t)2 * C * 9 * C * sizeof(float)) return PA2D_ERR_WORKSPACE;
+    if (ws_bytes < (size_t)3 * C * 9 * C * sizeof(float)) return PA2D_ERR_WORKSPACE;
     float* pack = (float*)ws;
-    int rc = launch_repack(wx, wf, pack, 1, 0, conv_chunk(C, 2 * C), C, C, st);
-    if (rc) return rc;
+    int rc = PA2D_OK;
+    const bool presplit_f = use_split(2 * C, true, C);
+    if (presplit_f) {
+        hipLaunchKernelGGL(repack_split_kernel, dim3((unsigned)ceil_div_ll((long long)2 * C * 9 * C, 256)), dim3(256), 0, st,
+                           wx, wf, (__bf16*)pack, 0, gemm_mode() == 2 ? 1 : 3, C, C);
+        PA2D_CHECK_LAUNCH();
+    } else {
+        rc = launch_repack(wx, wf, pack, 1, 0, 16, C, C, st);
+        if (rc) return rc;
+    }
     hipError_t e = hipMemcpyAsync(bias2_ws, bx, C * sizeof(float), hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) return (int)e;
     e = hipMemcpyAsync(bias2_ws + C, bf, C * sizeof(float), hipMemcpyDeviceToDevice, st);
@@ -973,12 +1059,18 @@ int pa2d_conv3x3x2_bwd(const float* dout, const float* xn, const float* wx, cons
                        hipEvent_t ev_stop) {
     if (ws_bytes < pa2d_conv3x3x2_workspace(B, H, W, C)) return PA2D_ERR_WORKSPACE;
     float* pack = (float*)ws;
-    float* scratch = pack + (size_t)2 * C * 9 * C;
+    float* scratch = pack + (size_t)3 * C * 9 * C;
     const int M = B * H * W;
     int rc;
     if (dxn) {
-        rc = launch_repack(wx, wf, pack, 2, 0, conv_chunk(2 * C, C), C, C, st);
-        if (rc) return rc;
+        if (use_split(C, true, 2 * C)) {
+            hipLaunchKernelGGL(repack_split_kernel, dim3((unsigned)ceil_div_ll((long long)2 * C * 9 * C, 256)), dim3(256), 0,
+                               st, wx, wf, (__bf16*)pack, 1, gemm_mode() == 2 ? 1 : 3, C, C);
+            PA2D_CHECK_LAUNCH();
+        } else {
+            rc = launch_repack(wx, wf, pack, 2, 0, 16, C, C, st);
+            if (rc) return rc;
+        }
         KCParams p = {};
         p.A = dout; p.lda = 2 * C; p.B = pack; p.ldb = 9 * 2 * C; p.C = dxn; p.ldc = C;
         p.M = M; p.N = C; p.K = 9 * 2 * C; p.H = H; p.W = W; p.Cin = 2 * C;
