@@ -33,6 +33,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 from transformerbasednavierstokesolver_amd import synth, harness, ops, ddp  # noqa: E402
+from transformerbasednavierstokesolver_amd.optim import FusedAdamW  # noqa: E402
+from transformerbasednavierstokesolver_amd.utils.testloss import TestLoss, FusedTestLoss  # noqa: E402
 
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md, chip-level parameters
 CONV_KERNEL = "gemm_kc_kernel<128,128,2,2,true>"
@@ -107,6 +109,7 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rollout", action="store_true")
+    ap.add_argument("--torch-optim", action="store_true", help="torch.optim.AdamW + torch rel-L2 instead of the fused kernels")
     ap.add_argument("--gemm-mode", type=int, default=0,
                     help="0 = exact fp32 MFMA (the metric of record), 2 = bf16-compute mode (BASELINE configs[2] numerics)")
     args = ap.parse_args()
@@ -138,12 +141,17 @@ def main():
     sd = synth.synth_state_dict(cfg, seed=0)          # identical on every rank
     model = harness.build_model(cfg, sd, dev).train()
     total_steps = args.steps + args.warmup
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-5)
+    if args.torch_optim:
+        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-5)
+        loss_fn = TestLoss(size_average=False)
+    else:   # fused multi-tensor AdamW + fused rel-L2 (libpa2d), same arithmetic
+        opt = FusedAdamW(model.parameters(), lr=1e-3, weight_decay=1e-5)
+        loss_fn = FusedTestLoss(size_average=False)
     sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-3, total_steps=max(total_steps, 2) + 1)
     log(f"rank {rank}/{world}: model built, generating {B} synthetic trajectories")
     pos, a, u = synth.ns_batch(B, seed=100 + rank)    # this rank's shard of the global batch
     x, fx, yy = (torch.from_numpy(t).to(dev) for t in (pos, a, u))
-    sync = ddp.FlatGradSync(model.parameters())
+    sync = ddp.FlatGradSync(model.parameters()) if args.torch_optim else opt.sync
 
     # parity sample before the weights move: teacher-forced predictions with the initial weights
     # (run at the full batch so that every launch of the dominant kernel in this process has the
@@ -157,7 +165,7 @@ def main():
     ops.conv_event_provider = pool.provider
 
     def step():
-        return harness.train_step(model, opt, sched, x, fx, yy, grad_sync=sync)
+        return harness.train_step(model, opt, sched, x, fx, yy, grad_sync=sync, loss_fn=loss_fn)
 
     for i in range(args.warmup):
         step()
@@ -209,7 +217,7 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.gemm_mode == 0 else ("f32 via 6-term bf16 split (conv)" if args.gemm_mode == 1 else "bf16 MFMA compute, f32 accumulate+storage"), "data": "synthetic",
         "config": {"workload": "exp_ns.py training iteration on NS 64x64 (10 teacher-forced Transolver calls + "
                                "backward + AdamW/OneCycleLR): Transolver_Structured_Mesh_2D 8 layers, C=256, 8 heads, "
-                               "M=64 slices, fp32, batch 32/GPU (BASELINE configs[1])",
+                               f"M=64 slices, fp32, batch {B}/GPU (BASELINE configs[1])",
                    "global_batch": world * B, "batch_per_gpu": B, "parallelism": f"dp{world}",
                    "model_calls_per_step": calls, "grad_allreduce_bytes": sync.nbytes},
         "model_call_samples_per_s": round(world * B * args.steps * calls / dt, 2),
@@ -250,6 +258,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

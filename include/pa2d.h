@@ -136,6 +136,22 @@ int pa2d_head_bwd(const float* dy, const float* xn, const float* w, float* dxn, 
  * (MLP hidden layers with n_layers > 0, …_2D.py:28,32-36; not used by the NS/Darcy configurations) */
 int pa2d_act_bwd(const float* dy, const float* pre, float* out, long long n, int act, pa2d_stream_t stream);
 
+/* ---- optimizer / loss side of the exp_ns iteration over flat fp32 buffers
+ * (exp_ns.py:198-218: TestLoss rel-L2 sum, clip_grad_norm_, AdamW.step; lr/beta1 of the step come from
+ * OneCycleLR on the host).  Buffers 16-byte aligned. */
+size_t pa2d_sumsq_workspace(long long n);
+int pa2d_sumsq(const float* g, long long n, float* out, void* ws, size_t ws_bytes, pa2d_stream_t stream);
+/* one multi-tensor AdamW update of p (decoupled weight decay, bias correction for step_index >= 1);
+ * gnorm_sq (device scalar, may be NULL) + max_norm > 0 apply clip_grad_norm_'s coefficient on the fly */
+int pa2d_adamw_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int step_index, const float* gnorm_sq, float max_norm,
+                    pa2d_stream_t stream);
+/* per-sample ||pred-y||, ||y|| and their ratio (utils/testloss.py:31-42), and the gradient w.r.t. pred */
+int pa2d_rel_l2_fwd(const float* pred, const float* y, float* dnorm, float* ynorm, float* ratio, int B,
+                    long long L, pa2d_stream_t stream);
+int pa2d_rel_l2_bwd(const float* pred, const float* y, const float* dnorm, const float* ynorm,
+                    const float* gout, float* dpred, int B, long long L, pa2d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,89 @@
+"""fused AdamW (+ OneCycleLR-driven lr/beta1, grad-norm clip) and fused rel-L2 loss
+against torch.optim.AdamW / clip_grad_norm_ / the reference TestLoss formula on the GPU."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _toy():
+    torch.manual_seed(5)
+    m = torch.nn.Sequential(torch.nn.Linear(37, 53), torch.nn.GELU(), torch.nn.Linear(53, 3)).to(DEV)
+    m.unused = torch.nn.Parameter(torch.rand(7, device=DEV))        # never receives a gradient
+    return m
+
+
+@pytest.mark.parametrize("clip", [None, 0.05])
+def test_fused_adamw_matches_torch_with_onecycle(clip):
+    from transformerbasednavierstokesolver_amd.optim import FusedAdamW
+    a, b = _toy(), _toy()
+    oa = torch.optim.AdamW(a.parameters(), lr=1e-3, weight_decay=1e-5)
+    ob = FusedAdamW(b.parameters(), lr=1e-3, weight_decay=1e-5, max_grad_norm=clip)
+    sa = torch.optim.lr_scheduler.OneCycleLR(oa, max_lr=1e-3, total_steps=12)
+    sb = torch.optim.lr_scheduler.OneCycleLR(ob, max_lr=1e-3, total_steps=12)
+    g = torch.Generator(device=DEV).manual_seed(1)
+    for it in range(6):
+        x = torch.randn(64, 37, device=DEV, generator=g)
+        for m, o, s in ((a, oa, sa), (b, ob, sb)):
+            o.zero_grad()
+            (m(x).square().sum() * 3.0).backward()
+            if o is oa and clip is not None:
+                torch.nn.utils.clip_grad_norm_(a.parameters(), clip)
+            o.step()
+            s.step()
+    for (ka, pa), (kb, pb) in zip(a.named_parameters(), b.named_parameters()):
+        assert ka == kb
+        assert rel_l2(pb, pa) < 2e-6, ka
+    assert b.unused.grad is None and torch.equal(a.unused, b.unused)
+    assert abs(sa.get_last_lr()[0] - sb.get_last_lr()[0]) < 1e-15
+    assert oa.param_groups[0]["betas"][0] == ob.param_groups[0]["betas"][0]
+
+
+@pytest.mark.parametrize("B,L", [(2, 60), (32, 4096), (5, 40960)])
+def test_fused_rel_l2_loss_and_gradient(B, L):
+    from transformerbasednavierstokesolver_amd.utils.testloss import TestLoss, FusedTestLoss
+    g = torch.Generator(device=DEV).manual_seed(B + L)
+    pred = torch.randn(B, L, device=DEV, generator=g)
+    y = torch.randn(B, L, device=DEV, generator=g)
+    for avg in (False, True):
+        p1 = pred.clone().requires_grad_(True)
+        p2 = pred.double().clone().requires_grad_(True)
+        l1 = FusedTestLoss(size_average=avg)(p1, y)
+        l2 = TestLoss(size_average=avg)(p2, y.double())
+        l1.backward()
+        l2.backward()
+        assert abs(l1.item() - l2.item()) < 2e-6 * abs(l2.item())
+        assert rel_l2(p1.grad, p2.grad) < 5e-6
+
+
+def test_training_step_with_fused_optimizer_and_loss_matches_reference_fixture():
+    """G4 again (the reference's exp_ns iteration + AdamW/OneCycle step), now through FusedAdamW and
+    FusedTestLoss: parameters after the step must match the reference-made fixture."""
+    import os
+    from conftest import GOLDEN
+    from transformerbasednavierstokesolver_amd import synth, harness
+    from transformerbasednavierstokesolver_amd.optim import FusedAdamW
+    from transformerbasednavierstokesolver_amd.utils.testloss import FusedTestLoss
+    g = np.load(os.path.join(GOLDEN, "G4_train_iteration.npz"))
+    cfg = synth.NS_SMALL_CONFIG
+    m = harness.build_model(cfg, synth.synth_state_dict(cfg, seed=41), DEV).train()
+    pos, a, u = synth.ns_batch(2, seed=42)
+    x, fx, yy = (torch.from_numpy(t).to(DEV) for t in (pos, a, u))
+    opt = FusedAdamW(m.parameters(), lr=1e-3, weight_decay=1e-5)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-3, epochs=5, steps_per_epoch=7)
+    loss, full, _ = harness.train_iteration(m, x, fx, yy, loss_fn=FusedTestLoss(size_average=False))
+    assert abs(loss.item() - float(g["loss"])) < 1e-5 * float(g["loss"])
+    opt.zero_grad()
+    loss.backward()
+    opt.step()
+    sched.step()
+    for k, p in m.named_parameters():
+        ref = float(g["param1.norm." + k])
+        assert abs(float(p.detach().double().norm()) - ref) < 1e-5 * ref + 1e-12, k
+        s = p.detach().double().cpu().numpy().ravel()
+        stride = max(1, s.size // 65)
+        assert rel_l2(s[::stride][:65], g["param1.sample." + k]) < 1e-5, k

@@ -47,6 +47,12 @@ SIGNATURES = {
     "pa2d_head_bwd_workspace": (_sz, [_i, _i, _i]),
     "pa2d_head_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _st]),
     "pa2d_act_bwd": (_i, [_f, _f, _f, _ll, _i, _st]),
+    "pa2d_sumsq_workspace": (_sz, [_ll]),
+    "pa2d_sumsq": (_i, [_f, _ll, _f, _f, _sz, _st]),
+    "pa2d_adamw_step": (_i, [_f, _f, _f, _f, _ll, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _i, _f,
+                             C.c_float, _st]),
+    "pa2d_rel_l2_fwd": (_i, [_f, _f, _f, _f, _f, _i, _ll, _st]),
+    "pa2d_rel_l2_bwd": (_i, [_f, _f, _f, _f, _f, _f, _i, _ll, _st]),
 }
 
 ERRORS = {1001: "PA2D_ERR_ARG (alignment/shape contract)", 1002: "PA2D_ERR_UNSUPPORTED (size outside kernel grid)",

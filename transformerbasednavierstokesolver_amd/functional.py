@@ -184,3 +184,28 @@ def mlp(x, res, act, w1, b1, w2, b2):
 
 def head(xn, w, b):
     return HeadFn.apply(xn, w, b)
+
+
+class RelL2Fn(Function):
+    """Per-sample ||pred-y||_2 / ||y||_2 (utils/testloss.py:31-42) in one kernel; gradient w.r.t. pred."""
+
+    @staticmethod
+    def forward(ctx, pred, y):
+        B = pred.shape[0]
+        p2, y2 = pred.detach().reshape(B, -1).contiguous(), y.detach().reshape(B, -1).contiguous()
+        dn, yn, ratio = ops.rel_l2_fwd(p2, y2)
+        ctx.saved, ctx.shp = (p2, y2, dn, yn), pred.shape
+        return ratio
+
+    @staticmethod
+    def backward(ctx, gratio):
+        p2, y2, dn, yn = ctx.saved
+        # d ratio_b / d pred = (pred - y) / (dn_b * yn_b); fold the incoming per-sample gradient into yn
+        g = gratio.contiguous()
+        one = torch.ones(1, dtype=torch.float32, device=p2.device)
+        dpred = ops.rel_l2_bwd(p2, y2, dn, yn / g, one)
+        return dpred.view(ctx.shp), None
+
+
+def rel_l2(pred, y):
+    return RelL2Fn.apply(pred, y)

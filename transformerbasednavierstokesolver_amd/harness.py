@@ -53,10 +53,12 @@ def train_iteration(model, x, fx, yy, step=1, loss_fn=None):
 
 
 def train_step(model, optimizer, scheduler, x, fx, yy, step=1, max_grad_norm=None, grad_sync=None,
-               set_to_none=False):
+               set_to_none=False, loss_fn=None):
     """One full exp_ns.py:191-218 iteration.  `grad_sync` (DDP): callable run between backward and
-    the optimizer step (all-reduce SUM of the flat gradient bucket)."""
-    loss, full, _ = train_iteration(model, x, fx, yy, step)
+    the optimizer step (all-reduce SUM of the flat gradient bucket).  With `optim.FusedAdamW` pass
+    `grad_sync=optimizer.sync` (same bucket) and put the clip threshold in the optimizer instead of
+    `max_grad_norm`."""
+    loss, full, _ = train_iteration(model, x, fx, yy, step, loss_fn)
     optimizer.zero_grad(set_to_none=set_to_none)
     loss.backward()
     if grad_sync is not None:

@@ -237,3 +237,37 @@ def act_bwd(dy, pre, act):
     out = torch.empty_like(dy)
     _lib.check(_L().pa2d_act_bwd(_p(dy), _p(pre), _p(out), dy.numel(), ACT_IDS[act], _stream()), "act_bwd")
     return out
+
+
+# ---------------------------------------------------------------------------------------------- SURVEY 8(f)-1
+def sumsq(flat):
+    _chk(flat)
+    out = torch.empty(1, dtype=torch.float32, device=flat.device)
+    nb = _L().pa2d_sumsq_workspace(flat.numel())
+    ws = _ws(nb, flat)
+    _lib.check(_L().pa2d_sumsq(_p(flat), flat.numel(), _p(out), ws.data_ptr(), nb, _stream()), "sumsq")
+    return out
+
+
+def adamw_step(p, g, m, v, lr, beta1, beta2, eps, weight_decay, step_index, gnorm_sq=None, max_norm=0.0):
+    _chk(p, g, m, v, gnorm_sq)
+    _lib.check(_L().pa2d_adamw_step(_p(p), _p(g), _p(m), _p(v), p.numel(), lr, beta1, beta2, eps, weight_decay,
+                                    step_index, _p(gnorm_sq), max_norm, _stream()), "adamw_step")
+
+
+def rel_l2_fwd(pred2d, y2d):
+    _chk(pred2d, y2d)
+    B, L = pred2d.shape
+    dn = torch.empty(B, dtype=torch.float32, device=pred2d.device)
+    yn, ratio = torch.empty_like(dn), torch.empty_like(dn)
+    _lib.check(_L().pa2d_rel_l2_fwd(_p(pred2d), _p(y2d), _p(dn), _p(yn), _p(ratio), B, L, _stream()), "rel_l2_fwd")
+    return dn, yn, ratio
+
+
+def rel_l2_bwd(pred2d, y2d, dn, yn, gout):
+    _chk(pred2d, y2d, dn, yn, gout)
+    B, L = pred2d.shape
+    dpred = torch.empty_like(pred2d)
+    _lib.check(_L().pa2d_rel_l2_bwd(_p(pred2d), _p(y2d), _p(dn), _p(yn), _p(gout), _p(dpred), B, L, _stream()),
+               "rel_l2_bwd")
+    return dpred

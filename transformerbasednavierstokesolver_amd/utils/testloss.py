@@ -28,3 +28,14 @@ class TestLoss(object):
 
     def __call__(self, x, y):
         return self.rel(x, y)
+
+
+class FusedTestLoss(TestLoss):
+    """TestLoss whose `rel` runs on the libpa2d rel-L2 kernels (p=2, fp32 GPU tensors) — SURVEY 8(f)-1."""
+    __test__ = False
+
+    def rel(self, x, y):
+        if self.p != 2 or not x.is_cuda:
+            return super().rel(x, y)
+        from ..functional import rel_l2
+        return self._reduce(rel_l2(x, y))
