@@ -168,7 +168,7 @@ def timestep_embedding(t, dim, max_period=10000):
     """t: [B,1] (exp_plas.py:186 passes `tim[:, t:t+1].reshape(bsz, 1)`) -> [B,1,dim], always
     computed in float32 like the reference."""
     half = dim // 2
-    freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32) / half)
+    freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
     args = t.reshape(-1, 1, 1).float() * freqs[None, None, :]
     emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
     if dim % 2:
