@@ -91,11 +91,12 @@ int pa2d_conv3x3x2_bwd(const float* dout, const float* xn, const float* wx, cons
  * N points into M tokens, Physics_Attention.py:98-101.  Emits per-chunk partial sums
  * spart [B,heads,nchunk,M,D] and npart [B,heads,nchunk,M] (npart NULL = skip), nchunk =
  * pa2d_slice_nchunk(B,N,heads); `v` is fx_mid in the forward and dY in backward phase A.
- * D in {8,16,32,64}, M <= 128. */
+ * D in {8,16,32,64}, M <= 128.  clamp_temperature: 1 = clamp(temperature, 0.1, 5) as the structured-mesh
+ * attention does (Physics_Attention.py:98-99); 0 = raw temperature (irregular mesh, :40). */
 int pa2d_slice_nchunk(int B, int N, int heads);
 int pa2d_slice_scatter(const float* xm, long long ldx, const float* v, long long ldv, const float* ws,
                        const float* bs, const float* temperature, float* spart, float* npart, int B, int N,
-                       int heads, int D, int M, pa2d_stream_t stream);
+                       int heads, int D, int M, int clamp_temperature, pa2d_stream_t stream);
 
 /* ---- token attention among the M slice tokens of each (batch, head): normalisation by
  * (slice_norm + 1e-5), to_q/to_k/to_v, softmax(q k^T D^-0.5), attn.v — Physics_Attention.py:102-111.
@@ -113,7 +114,7 @@ int pa2d_token_attn_bwd(const float* s, const float* nrm, const float* wq, const
  * (Physics_Attention.py:116-117); slice weights are recomputed from x_mid, never stored. */
 int pa2d_deslice_fwd(const float* xm, long long ldx, const float* o, const float* ws, const float* bs,
                      const float* temperature, float* y, long long ldy, int B, int N, int heads, int D, int M,
-                     pa2d_stream_t stream);
+                     int clamp_temperature, pa2d_stream_t stream);
 
 /* ---- backward of slice + de-slice w.r.t. the points (autograd of
  * Physics_Attention.py:98-101,116): given dY, O, dS, dn produces dx_mid, dfx_mid and the fully
@@ -123,7 +124,8 @@ int pa2d_slice_bwd_points(const float* xm, long long ldx, const float* fm, long 
                           long long lddy, const float* ws, const float* bs, const float* temperature,
                           const float* o, const float* ds, const float* dn, float* dxm, long long lddx,
                           float* dfm, long long lddf, float* dws, float* dbs, float* dtemperature, void* ws_buf,
-                          size_t ws_bytes, int B, int N, int heads, int D, int M, pa2d_stream_t stream);
+                          size_t ws_bytes, int B, int N, int heads, int D, int M, int clamp_temperature,
+                          pa2d_stream_t stream);
 
 /* ---- output head mlp2 = nn.Linear(C, out_dim), out_dim <= 8 (…_2D.py:66,73) */
 int pa2d_head_fwd(const float* xn, const float* w, const float* b, float* y, int rows, int C, int out_dim,

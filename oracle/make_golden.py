@@ -270,6 +270,44 @@ def g5_full_ns(Model, TestLoss):
     np.savez_compressed(os.path.join(GOLD, "G5_full_ns.npz"), **out)
 
 
+def g6_irregular():
+    """the irregular-mesh family (exp_elas.py geometry: 972 points, C=128, 8 heads, M=64,
+    fun_dim=0, `model(x, None)`), reference in fp64: output + all gradients (strided samples + norms);
+    plus a tiny unified_pos + fx case stored in full."""
+    from model.Transolver_Irregular_Mesh import Model as IModel
+    out = {}
+    for tag, cfg, B, N, seed in (("elas", synth.make_config(n_layers=3, n_hidden=128, n_head=8, slice_num=64, fun_dim=0,
+                                                           out_dim=1, unified_pos=0), 2, 972, 111),
+                                 ("tiny", synth.make_config(n_layers=2, n_hidden=32, n_head=4, slice_num=12, fun_dim=3,
+                                                           out_dim=2, unified_pos=1, ref=3, mlp_ratio=2), 2, 45, 113)):
+        sd = synth.synth_irregular_state_dict(cfg, seed=seed)
+        m = IModel(space_dim=2, n_layers=cfg["n_layers"], n_hidden=cfg["n_hidden"], dropout=0.0, n_head=cfg["n_head"],
+                   Time_Input=False, mlp_ratio=cfg["mlp_ratio"], fun_dim=cfg["fun_dim"], out_dim=cfg["out_dim"],
+                   slice_num=cfg["slice_num"], ref=cfg["ref"], unified_pos=cfg["unified_pos"])
+        res = m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+        assert not res.missing_keys and not res.unexpected_keys
+        m = m.double()
+        rng = np.random.default_rng(seed + 1)
+        x = rng.uniform(0, 1, (B, N, 2)).astype(np.float32)
+        fx = rng.standard_normal((B, N, cfg["fun_dim"])).astype(np.float32) if cfg["fun_dim"] else None
+        gy = rng.standard_normal((B, N, cfg["out_dim"])).astype(np.float32)
+        xt = torch.from_numpy(x).double()
+        fxt = None if fx is None else torch.from_numpy(fx).double()
+        pred = m(xt, fxt)
+        pred.backward(torch.from_numpy(gy).double())
+        sdo = orc.to_torch(sd, torch.float64, requires_grad=True)
+        po = orc.model_forward_irregular(sdo, xt, fxt, cfg)
+        po.backward(torch.from_numpy(gy).double())
+        check(f"G6 {tag} forward", po.detach(), pred.detach(), 1e-12)
+        out[f"{tag}.pred.sample"], _ = sample(pred.detach())
+        out[f"{tag}.pred.norm"] = np.asarray(float(pred.detach().norm()))
+        for k, p in m.named_parameters():
+            check(f"G6 {tag} grad {k}", sdo[k].grad, p.grad, 1e-9)
+            out[f"{tag}.grad.norm.{k}"] = np.asarray(float(p.grad.norm()))
+            out[f"{tag}.grad.sample.{k}"], _ = sample(p.grad, 65)
+    np.savez(os.path.join(GOLD, "G6_irregular.npz"), **out)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
@@ -277,7 +315,9 @@ def main():
     for name, fn in (("G1", lambda: g1_tiny(Model, TestLoss)), ("G1b", lambda: g1b_tiny_branches(Model)),
                      ("G2", lambda: g2_attn(Attn)), ("G3", lambda: g3_shipped_rollout(Model)),
                      ("G4", lambda: g4_train_iteration(Model, TestLoss)),
-                     ("G5", lambda: g5_full_ns(Model, TestLoss))):
+                     ("G5", lambda: g5_full_ns(Model, TestLoss)), ("G6", g6_irregular)):
+        if len(sys.argv) > 1 and name not in sys.argv[1:]:
+            continue
         print(name)
         fn()
     print("golden fixtures written to", GOLD)

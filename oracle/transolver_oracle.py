@@ -26,6 +26,8 @@ Reference lines each function follows (relative to the reference repo root):
   train_iteration        exp_ns.py:191-218
   rollout                exp_ns.py:225-241, ns_vorticity_unrolling.py:264-286
   timestep_embedding     model/Embedding.py:67-85
+  physics_attention_irregular, model_forward_irregular
+                         model/Physics_Attention.py:6-57, model/Transolver_Irregular_Mesh.py:137-158
   unrolled_iteration_loss  ns_vorticity_unrolling.py:225-244
   central_diff, darcy_loss exp_darcy.py:59-68, 216-227
 """
@@ -136,6 +138,43 @@ def physics_attention(xn, sd, pre, H, W, h, want=None):
     if want is not None:
         want.update(xm=xm, fm=fm, w=w, norm=norm, s=s, tok=tok, o=o, y=y, out=out)
     return out
+
+
+def physics_attention_irregular(xn, sd, pre, h):
+    """model/Physics_Attention.py:6-57: Linear projections, temperature NOT clamped."""
+    xm = xn @ sd[pre + "in_project_x.weight"].t() + sd[pre + "in_project_x.bias"]
+    fm = xn @ sd[pre + "in_project_fx.weight"].t() + sd[pre + "in_project_fx.bias"]
+    logits = (split_heads(xm, h) @ sd[pre + "in_project_slice.weight"].t() + sd[pre + "in_project_slice.bias"]) \
+        / sd[pre + "temperature"].reshape(1, -1, 1, 1)
+    w = torch.softmax(logits, dim=-1)
+    norm = w.sum(2)
+    tok = (w.transpose(-1, -2) @ split_heads(fm, h)) / (norm + SLICE_EPS)[..., None]
+    o = token_attention(tok, sd[pre + "to_q.weight"], sd[pre + "to_k.weight"], sd[pre + "to_v.weight"])
+    return deslice(w, o) @ sd[pre + "to_out.0.weight"].t() + sd[pre + "to_out.0.bias"]
+
+
+def model_forward_irregular(sd, x, fx, cfg, T=None):
+    """model/Transolver_Irregular_Mesh.py:137-158 (placeholder ALWAYS added; unified_pos from x)."""
+    h, act = cfg["n_head"], cfg.get("act", "gelu")
+    if cfg["unified_pos"]:
+        ref = cfg["ref"]
+        r = torch.tensor(np.linspace(0, 1, ref), dtype=torch.float32).to(x.dtype).to(x.device)
+        grid = torch.stack((r.reshape(ref, 1).expand(ref, ref), r.reshape(1, ref).expand(ref, ref)), -1).reshape(1, ref * ref, 2)
+        x = torch.sqrt(((x[:, :, None, :] - grid[:, None, :, :]) ** 2).sum(-1))
+    z = mlp(torch.cat((x, fx), -1) if fx is not None else x, sd, "preprocess.", act) + sd["placeholder"][None, None, :]
+    if T is not None:
+        C = sd["placeholder"].shape[0]
+        e = timestep_embedding(T, C).to(z.dtype)
+        e = F.silu(e @ sd["time_fc.0.weight"].t() + sd["time_fc.0.bias"])
+        z = z + (e @ sd["time_fc.2.weight"].t() + sd["time_fc.2.bias"])
+    L = 1 + max(int(k.split(".")[1]) for k in sd if k.startswith("blocks."))
+    for i in range(L):
+        p = f"blocks.{i}."
+        z = physics_attention_irregular(layer_norm(z, sd[p + "ln_1.weight"], sd[p + "ln_1.bias"]), sd, p + "Attn.", h) + z
+        z = mlp(layer_norm(z, sd[p + "ln_2.weight"], sd[p + "ln_2.bias"]), sd, p + "mlp.", act) + z
+        if i == L - 1:
+            z = layer_norm(z, sd[p + "ln_3.weight"], sd[p + "ln_3.bias"]) @ sd[p + "mlp2.weight"].t() + sd[p + "mlp2.bias"]
+    return z
 
 
 def gelu_erf(x):

@@ -258,3 +258,30 @@ def test_bf16_compute_mode_full_ns_model():
         lib.pa2d_set_gemm_mode(0)
     assert 1e-5 < e < 3e-2, e          # really ran in reduced precision, and within the bf16 tolerance
     assert all(torch.isfinite(p.grad).all() for k, p in m.named_parameters() if p.grad is not None)
+
+
+@pytest.mark.parametrize("tag", ["elas", "tiny"])
+def test_g6_irregular_mesh_model(tag):
+    """Transolver_Irregular_Mesh.Model (exp_elas.py geometry and a tiny unified_pos case)
+    on the HIP kernels vs the reference-made fixture: Linear projections, unclamped temperature (values
+    outside [0.1, 5] included), placeholder always added (and receiving a gradient)."""
+    from test_oracle_golden import g6_inputs
+    from transformerbasednavierstokesolver_amd.model_dict import get_model
+    import types
+    g = np.load(os.path.join(GOLDEN, "G6_irregular.npz"))
+    cfg, sd, x, fx, gy = g6_inputs(tag)
+    Model = get_model(types.SimpleNamespace(model="Transolver_Irregular_Mesh")).Model
+    m = Model(space_dim=2, n_layers=cfg["n_layers"], n_hidden=cfg["n_hidden"], dropout=0.0, n_head=cfg["n_head"],
+              Time_Input=False, mlp_ratio=cfg["mlp_ratio"], fun_dim=cfg["fun_dim"], out_dim=cfg["out_dim"],
+              slice_num=cfg["slice_num"], ref=cfg["ref"], unified_pos=cfg["unified_pos"])
+    res = m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    m = m.to(DEV)
+    pred = m(torch.from_numpy(x).to(DEV), None if fx is None else torch.from_numpy(fx).to(DEV))
+    pred.backward(torch.from_numpy(gy).to(DEV))
+    assert rel_l2(_sample(pred), g[f"{tag}.pred.sample"]) < 1e-5
+    for k, p in m.named_parameters():
+        tol = _grad_tol(k)
+        assert rel_l2(_sample(p.grad, 65), g[f"{tag}.grad.sample.{k}"]) < tol, k
+        ref = float(g[f"{tag}.grad.norm.{k}"])
+        assert abs(float(p.grad.double().norm()) - ref) < tol * ref, k

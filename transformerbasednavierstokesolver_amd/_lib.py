@@ -34,15 +34,15 @@ SIGNATURES = {
     "pa2d_conv3x3x2_fwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _i, _st, _st, _st]),
     "pa2d_conv3x3x2_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _i, _st, _st, _st]),
     "pa2d_slice_nchunk": (_i, [_i, _i, _i]),
-    "pa2d_slice_scatter": (_i, [_f, _ll, _f, _ll, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _st]),
+    "pa2d_slice_scatter": (_i, [_f, _ll, _f, _ll, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _st]),
     "pa2d_token_attn_lds_bytes": (_sz, [_i, _i, _i]),
     "pa2d_token_attn_fwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _st]),
     "pa2d_token_attn_bwd_workspace": (_sz, [_i, _i]),
     "pa2d_token_attn_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _i, _st]),
-    "pa2d_deslice_fwd": (_i, [_f, _ll, _f, _f, _f, _f, _f, _ll, _i, _i, _i, _i, _i, _st]),
+    "pa2d_deslice_fwd": (_i, [_f, _ll, _f, _f, _f, _f, _f, _ll, _i, _i, _i, _i, _i, _i, _st]),
     "pa2d_slice_bwd_workspace": (_sz, [_i, _i, _i, _i, _i]),
     "pa2d_slice_bwd_points": (_i, [_f, _ll, _f, _ll, _f, _ll, _f, _f, _f, _f, _f, _f, _f, _ll, _f, _ll, _f, _f, _f,
-                                   _f, _sz, _i, _i, _i, _i, _i, _st]),
+                                   _f, _sz, _i, _i, _i, _i, _i, _i, _st]),
     "pa2d_head_fwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _st]),
     "pa2d_head_bwd_workspace": (_sz, [_i, _i, _i]),
     "pa2d_head_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _st]),

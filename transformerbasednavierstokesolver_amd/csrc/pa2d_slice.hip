@@ -108,6 +108,7 @@ struct SliceParams {
     float* spart; float* npart;         // [B,heads,nchunk,M,D], [B,heads,nchunk,M] (npart may be null)
     int B, N, heads, M, nchunk, ppc;    // ppc = points per chunk (multiple of 16)
     unsigned x_bytes, v_bytes;          // extents for the buffer descriptors
+    int clamp;                          // 1: clamp(temperature, .1, 5) (structured mesh); 0: raw (irregular mesh)
 };
 
 // S_partial[m][d] = sum_{n in chunk} W[n][m] * V[n][d];  n_partial[m] = sum_n W[n][m]
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256) void slice_scatter_kernel(const SliceParams p)
     const int chunk = blockIdx.x % p.nchunk;
     const int hh = (blockIdx.x / p.nchunk) % p.heads;
     const int b = blockIdx.x / (p.nchunk * p.heads);
-    const float inv_tau = 1.0f / clamp_tau(p.temperature[hh]);
+    const float inv_tau = 1.0f / (p.clamp ? clamp_tau(p.temperature[hh]) : p.temperature[hh]);
 
     float wsf[MT][KS], bsv[MT];
 #pragma unroll
@@ -242,6 +243,7 @@ struct DesliceParams {
     float* y; long long ldy;            // y[(b*N+n)*ldy + h*D + d]
     int B, N, heads, M, nchunk, ppc;
     unsigned x_bytes, y_bytes;
+    int clamp;
 };
 
 // Y[n][h*D+d] = sum_m W[n][m] * O[m][d]
@@ -252,7 +254,7 @@ __global__ __launch_bounds__(256) void deslice_kernel(const DesliceParams p) {
     const int chunk = blockIdx.x % p.nchunk;
     const int hh = (blockIdx.x / p.nchunk) % p.heads;
     const int b = blockIdx.x / (p.nchunk * p.heads);
-    const float inv_tau = 1.0f / clamp_tau(p.temperature[hh]);
+    const float inv_tau = 1.0f / (p.clamp ? clamp_tau(p.temperature[hh]) : p.temperature[hh]);
 
     float wsf[MT][KS], bst[MT][4], of[MT][4][DT];
     const float* ob = p.o + (size_t)(b * p.heads + hh) * p.M * D;
@@ -344,6 +346,7 @@ struct SliceBwdParams {
     float* part;                        // per block: [M*D (dWs) | M (dbs) | 1 (dtau)]
     int B, N, heads, M, nchunk, ppc;
     unsigned x_bytes, f_bytes, dy_bytes, dx_bytes, df_bytes;
+    int clamp;
 };
 
 // Backward phase C (per point): recompute W, then
@@ -368,7 +371,7 @@ __global__ __launch_bounds__(256) void slice_bwd_kernel(const SliceBwdParams p) 
     const int chunk = blockIdx.x % p.nchunk;
     const int hh = (blockIdx.x / p.nchunk) % p.heads;
     const int b = blockIdx.x / (p.nchunk * p.heads);
-    const float inv_tau = 1.0f / clamp_tau(p.temperature[hh]);
+    const float inv_tau = 1.0f / (p.clamp ? clamp_tau(p.temperature[hh]) : p.temperature[hh]);
     const size_t bh = (size_t)(b * p.heads + hh);
 
     for (int i = tid; i < MP * P; i += 256) {
@@ -604,14 +607,15 @@ __global__ __launch_bounds__(256) void slice_bwd_kernel(const SliceBwdParams p) 
 
 // dtemperature[h] = mask(0.1 <= t <= 5) * sum over (b, chunk) of the per-block dtau partials
 __global__ void dtau_finalize_kernel(const float* __restrict__ part, const float* __restrict__ temperature,
-                                     float* __restrict__ dtemp, int B, int heads, int nchunk, int stride, int off) {
+                                     float* __restrict__ dtemp, int B, int heads, int nchunk, int stride, int off,
+                                     int clamp) {
     const int hh = blockIdx.x * blockDim.x + threadIdx.x;
     if (hh >= heads) return;
     float s = 0.f;
     for (int b = 0; b < B; ++b)
         for (int c = 0; c < nchunk; ++c) s += part[(size_t)((b * heads + hh) * nchunk + c) * stride + off];
     const float t = temperature[hh];
-    dtemp[hh] = (t >= 0.1f && t <= 5.0f) ? s : 0.f;
+    dtemp[hh] = (!clamp || (t >= 0.1f && t <= 5.0f)) ? s : 0.f;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -684,12 +688,12 @@ static int ppc_for(int N, int nchunk) { return ceil_div(ceil_div(N, nchunk), 16)
 // spart [B,heads,nchunk,M,D], npart [B,heads,nchunk,M] (NULL to skip the norm)
 int pa2d_slice_scatter(const float* xm, long long ldx, const float* v, long long ldv, const float* ws,
                        const float* bs, const float* temperature, float* spart, float* npart, int B, int N,
-                       int heads, int D, int M, hipStream_t st) {
+                       int heads, int D, int M, int clamp_temperature, hipStream_t st) {
     const int mt = mt_for(M);
     if ((ldx & 3) || (D & 7)) return PA2D_ERR_ARG;
     SliceParams p;
     p.xm = xm; p.ldx = ldx; p.v = v; p.ldv = ldv; p.ws = ws; p.bs = bs; p.temperature = temperature;
-    p.spart = spart; p.npart = npart; p.B = B; p.N = N; p.heads = heads; p.M = M;
+    p.spart = spart; p.npart = npart; p.B = B; p.N = N; p.heads = heads; p.M = M; p.clamp = clamp_temperature;
     p.nchunk = pa2d_slice_nchunk(B, N, heads);
     p.ppc = ppc_for(N, p.nchunk);
     {
@@ -708,12 +712,12 @@ int pa2d_slice_scatter(const float* xm, long long ldx, const float* v, long long
 
 int pa2d_deslice_fwd(const float* xm, long long ldx, const float* o, const float* ws, const float* bs,
                      const float* temperature, float* y, long long ldy, int B, int N, int heads, int D, int M,
-                     hipStream_t st) {
+                     int clamp_temperature, hipStream_t st) {
     const int mt = mt_for(M);
     if ((ldx & 3) || (ldy & 3) || (D & 7)) return PA2D_ERR_ARG;
     DesliceParams p;
     p.xm = xm; p.ldx = ldx; p.o = o; p.ws = ws; p.bs = bs; p.temperature = temperature; p.y = y; p.ldy = ldy;
-    p.B = B; p.N = N; p.heads = heads; p.M = M;
+    p.B = B; p.N = N; p.heads = heads; p.M = M; p.clamp = clamp_temperature;
     p.nchunk = pa2d_slice_nchunk(B, N, heads);
     p.ppc = ppc_for(N, p.nchunk);
     {
@@ -740,14 +744,14 @@ int pa2d_slice_bwd_points(const float* xm, long long ldx, const float* fm, long 
                           long long lddy, const float* ws, const float* bs, const float* temperature,
                           const float* o, const float* ds, const float* dn, float* dxm, long long lddx, float* dfm,
                           long long lddf, float* dws, float* dbs, float* dtemperature, void* ws_buf, size_t ws_bytes,
-                          int B, int N, int heads, int D, int M, hipStream_t st) {
+                          int B, int N, int heads, int D, int M, int clamp_temperature, hipStream_t st) {
     const int mt = mt_for(M);
     if ((ldx & 3) || (ldf & 3) || (lddy & 3) || (lddx & 3) || (lddf & 3) || (D & 7)) return PA2D_ERR_ARG;
     if (ws_bytes < pa2d_slice_bwd_workspace(B, N, heads, D, M)) return PA2D_ERR_WORKSPACE;
     SliceBwdParams p;
     p.xm = xm; p.ldx = ldx; p.fm = fm; p.ldf = ldf; p.dy = dy; p.lddy = lddy; p.ws = ws; p.bs = bs;
     p.temperature = temperature; p.o = o; p.ds = ds; p.dn = dn; p.dxm = dxm; p.lddx = lddx; p.dfm = dfm;
-    p.lddf = lddf; p.part = (float*)ws_buf; p.B = B; p.N = N; p.heads = heads; p.M = M;
+    p.lddf = lddf; p.part = (float*)ws_buf; p.B = B; p.N = N; p.heads = heads; p.M = M; p.clamp = clamp_temperature;
     p.nchunk = pa2d_slice_nchunk(B, N, heads);
     p.ppc = ppc_for(N, p.nchunk);
     {
@@ -776,7 +780,7 @@ int pa2d_slice_bwd_points(const float* xm, long long ldx, const float* fm, long 
     e = hipMemcpyAsync(dbs, tail + M * D, sizeof(float) * M, hipMemcpyDeviceToDevice, st);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(dtau_finalize_kernel, dim3(ceil_div(heads, 64)), dim3(64), 0, st, p.part, temperature,
-                       dtemperature, B, heads, p.nchunk, stride, M * D + M);
+                       dtemperature, B, heads, p.nchunk, stride, M * D + M, clamp_temperature);
     PA2D_CHECK_LAUNCH();
     return PA2D_OK;
 }

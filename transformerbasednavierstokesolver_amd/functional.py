@@ -14,15 +14,23 @@ from . import ops
 
 # ------------------------------------------------------------------------------ Physics-Attention
 def attn_forward(xn, P, res, H, W, heads):
-    """xn [B,N,C] (already layer-normed).  P: dict of parameter tensors.  Returns (out, saved)."""
+    """xn [B,N,C] (already layer-normed).  P: dict of parameter tensors.  Returns (out, saved).
+    H is None -> irregular-mesh variant (Physics_Attention.py:6-57): Linear projections, no
+    temperature clamp; otherwise the structured-mesh variant (3x3 conv projections, clamp)."""
     B, N, C = xn.shape
     D = C // heads
     M = P["ws"].shape[0]
     temp = P["temperature"].reshape(heads).contiguous()
-    xf = ops.conv3x3x2_fwd(xn, P["wx"], P["bx"], P["wf"], P["bf"], H, W)                       # [B,N,2C]
-    spart, npart = ops.slice_scatter(xf, 2 * C, 0, xf, 2 * C, C, P["ws"], P["bs"], temp, B, N, heads, D, M)
+    structured = H is not None
+    if structured:
+        xf = ops.conv3x3x2_fwd(xn, P["wx"], P["bx"], P["wf"], P["bf"], H, W)                   # [B,N,2C]
+    else:   # both Linear(C, C) projections as ONE GEMM with the weights stacked along the output dim
+        wcat, bcat = torch.cat((P["wx"], P["wf"]), 0), torch.cat((P["bx"], P["bf"]), 0)
+        xf = ops.linear_fwd(xn.view(B * N, C), wcat, bcat)[0].view(B, N, 2 * C)
+    spart, npart = ops.slice_scatter(xf, 2 * C, 0, xf, 2 * C, C, P["ws"], P["bs"], temp, B, N, heads, D, M,
+                                     clamp=structured)
     s, nrm, o = ops.token_attn_fwd(spart, npart, P["wq"], P["wk"], P["wv"])
-    y = ops.deslice_fwd(xf, 2 * C, 0, o, P["ws"], P["bs"], temp, B, N, heads, D, M)          # [B,N,C]
+    y = ops.deslice_fwd(xf, 2 * C, 0, o, P["ws"], P["bs"], temp, B, N, heads, D, M, clamp=structured)  # [B,N,C]
     out, _ = ops.linear_fwd(y.view(B * N, C), P["wo"], P["bo"],
                             res=None if res is None else res.reshape(B * N, C))
     return out.view(B, N, C), (xn, xf, s, nrm, o, y, temp)
@@ -36,11 +44,19 @@ def attn_backward(saved, P, dout, H, W, heads, need_dx=True):
     d2 = dout.reshape(B * N, C)
     dy = ops.linear_bwd_data(d2, P["wo"])                                                     # [B*N,C]
     dwo, dbo = ops.linear_bwd_weight(d2, y.view(B * N, C))
+    structured = H is not None
     dopart, _ = ops.slice_scatter(xf, 2 * C, 0, dy, C, 0, P["ws"], P["bs"], temp, B, N, heads, D, M,
-                                  want_norm=False)
+                                  want_norm=False, clamp=structured)
     ds, dn, dwq, dwk, dwv = ops.token_attn_bwd(s, nrm, P["wq"], P["wk"], P["wv"], dopart)
-    dxf, dws, dbs, dtemp = ops.slice_bwd_points(xf, dy, P["ws"], P["bs"], temp, o, ds, dn, B, N, heads, D, M)
-    dxn, dwx, dbx, dwf, dbf = ops.conv3x3x2_bwd(dxf, xn, P["wx"], P["wf"], H, W, need_dx=need_dx)
+    dxf, dws, dbs, dtemp = ops.slice_bwd_points(xf, dy, P["ws"], P["bs"], temp, o, ds, dn, B, N, heads, D, M,
+                                                clamp=structured)
+    if structured:
+        dxn, dwx, dbx, dwf, dbf = ops.conv3x3x2_bwd(dxf, xn, P["wx"], P["wf"], H, W, need_dx=need_dx)
+    else:
+        dxf2, xn2 = dxf.view(B * N, 2 * C), xn.view(B * N, C)
+        dwcat, dbcat = ops.linear_bwd_weight(dxf2, xn2)
+        dwx, dwf, dbx, dbf = dwcat[:C].contiguous(), dwcat[C:].contiguous(), dbcat[:C].contiguous(), dbcat[C:].contiguous()
+        dxn = ops.linear_bwd_data(dxf2, torch.cat((P["wx"], P["wf"]), 0)).view(B, N, C) if need_dx else None
     grads = dict(temperature=dtemp.view(1, heads, 1, 1), wx=dwx, bx=dbx, wf=dwf, bf=dbf, ws=dws, bs=dbs,
                  wq=dwq, wk=dwk, wv=dwv, wo=dwo, bo=dbo)
     return dxn, grads

@@ -148,14 +148,15 @@ def slice_nchunk(B, N, heads):
     return _L().pa2d_slice_nchunk(B, N, heads)
 
 
-def slice_scatter(xm, ldx, xm_off, v, ldv, v_off, ws_w, bs, temperature, B, N, heads, D, M, want_norm=True):
+def slice_scatter(xm, ldx, xm_off, v, ldv, v_off, ws_w, bs, temperature, B, N, heads, D, M, want_norm=True,
+                  clamp=True):
     """Partial sums of W^T V per point chunk.  xm / v are base tensors; *_off are float offsets."""
     _chk(xm, v, ws_w, bs, temperature)
     nchunk = slice_nchunk(B, N, heads)
     spart = torch.empty(B * heads, nchunk, M, D, dtype=torch.float32, device=xm.device)
     npart = torch.empty(B * heads, nchunk, M, dtype=torch.float32, device=xm.device) if want_norm else None
     _lib.check(_L().pa2d_slice_scatter(_p(xm, xm_off), ldx, _p(v, v_off), ldv, _p(ws_w), _p(bs), _p(temperature),
-                                       _p(spart), _p(npart), B, N, heads, D, M, _stream()), "slice_scatter")
+                                       _p(spart), _p(npart), B, N, heads, D, M, int(clamp), _stream()), "slice_scatter")
     return spart, npart
 
 
@@ -184,15 +185,15 @@ def token_attn_bwd(s, nrm, wq, wk, wv, dopart):
     return ds, dn, dwq, dwk, dwv
 
 
-def deslice_fwd(xm, ldx, xm_off, o, ws_w, bs, temperature, B, N, heads, D, M):
+def deslice_fwd(xm, ldx, xm_off, o, ws_w, bs, temperature, B, N, heads, D, M, clamp=True):
     _chk(xm, o, ws_w, bs, temperature)
     y = torch.empty(B, N, heads * D, dtype=torch.float32, device=xm.device)
     _lib.check(_L().pa2d_deslice_fwd(_p(xm, xm_off), ldx, _p(o), _p(ws_w), _p(bs), _p(temperature), _p(y), heads * D,
-                                     B, N, heads, D, M, _stream()), "deslice_fwd")
+                                     B, N, heads, D, M, int(clamp), _stream()), "deslice_fwd")
     return y
 
 
-def slice_bwd_points(xf, dy, ws_w, bs, temperature, o, ds, dn, B, N, heads, D, M):
+def slice_bwd_points(xf, dy, ws_w, bs, temperature, o, ds, dn, B, N, heads, D, M, clamp=True):
     """xf = [B,N,2C] ([x_mid | fx_mid]); returns dxf [B,N,2C], dws, dbs, dtemperature [heads]."""
     _chk(xf, dy, ws_w, bs, temperature, o, ds, dn)
     Cc = heads * D
@@ -205,7 +206,7 @@ def slice_bwd_points(xf, dy, ws_w, bs, temperature, o, ds, dn, B, N, heads, D, M
     _lib.check(_L().pa2d_slice_bwd_points(_p(xf), 2 * Cc, _p(xf, Cc), 2 * Cc, _p(dy), Cc, _p(ws_w), _p(bs),
                                           _p(temperature), _p(o), _p(ds), _p(dn), _p(dxf), 2 * Cc, _p(dxf, Cc),
                                           2 * Cc, _p(dws), _p(dbs), _p(dtemp), ws.data_ptr(), nb, B, N, heads, D, M,
-                                          _stream()), "slice_bwd_points")
+                                          int(clamp), _stream()), "slice_bwd_points")
     return dxf, dws, dbs, dtemp
 
 

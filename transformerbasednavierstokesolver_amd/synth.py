@@ -77,6 +77,39 @@ def state_dict_spec(cfg):
     return spec
 
 
+def irregular_state_dict_spec(cfg):
+    """state_dict of model/Transolver_Irregular_Mesh.Model: same keys, Linear [C,C] projections."""
+    out = []
+    for key, shape, kind in state_dict_spec(cfg):
+        if kind == "conv_w":
+            out.append((key, shape[:2], "lin_w"))
+        else:
+            out.append((key, shape, kind))
+    return out
+
+
+def synth_irregular_state_dict(cfg, seed=0):
+    rng = np.random.default_rng(seed)
+    sd = {}
+    for key, shape, kind in irregular_state_dict_spec(cfg):
+        if kind in ("lin_w",):
+            v = rng.standard_normal(shape) / np.sqrt(shape[1])
+        elif kind == "qk_w":
+            v = rng.standard_normal(shape) * (1.5 / np.sqrt(shape[1]))
+        elif kind == "slice_w":
+            v = rng.standard_normal(shape) / np.sqrt(shape[1])
+        elif kind == "bias":
+            v = 0.1 * rng.standard_normal(shape)
+        elif kind == "ln_w":
+            v = 1.0 + 0.1 * rng.standard_normal(shape)
+        elif kind == "temperature":          # NOT clamped in this family: include values outside [0.1, 5]
+            v = np.resize(np.array([0.06, 0.5, 6.0, 0.25, 1.5, 0.8, 0.3, 1.1]), shape[1]).reshape(shape)
+        else:
+            v = rng.uniform(0.0, 1.0, size=shape) / shape[0]
+        sd[key] = np.ascontiguousarray(v, dtype=np.float32)
+    return sd
+
+
 def synth_state_dict(cfg, seed=0, wild_temperature=False):
     """Deterministic fp32 weights (numpy) with O(1) activations through the whole stack.
 
