@@ -1,15 +1,17 @@
-"""Model registry — the reference's plug-in boundary (model_dict.py:4-11): `get_model(args)` returns a
-MODULE that exposes `Model`.  The structured-mesh-2D family is the hot path; the irregular-mesh family is §8(f)-2."""
-from .model import Transolver_Structured_Mesh_2D, Transolver_Irregular_Mesh
+"""Model registry — the reference's plug-in boundary: `get_model(args)` maps `args.model` to a MODULE
+exposing `Model` (reference model_dict.py).  The structured-mesh-2D family is the hot path;
+the irregular-mesh family is its §8(f)-2 widening; the other two reference families are not built."""
+from .model import Transolver_Irregular_Mesh, Transolver_Structured_Mesh_2D
 
-_OUT_OF_SCOPE = ('Transolver_Structured_Mesh_3D', 'Transolver_Structured_Mesh2D_Encoder')
+REGISTRY = {
+    "Transolver_Structured_Mesh_2D": Transolver_Structured_Mesh_2D,     # exp_ns / exp_darcy / exp_airfoil / exp_pipe / exp_plas
+    "Transolver_Irregular_Mesh": Transolver_Irregular_Mesh,             # exp_elas
+}
+NOT_BUILT = ("Transolver_Structured_Mesh_3D", "Transolver_Structured_Mesh2D_Encoder")
 
 
 def get_model(args):
-    model_dict = {
-        'Transolver_Irregular_Mesh': Transolver_Irregular_Mesh,          # SURVEY 8(f)-2 (exp_elas.py)
-        'Transolver_Structured_Mesh_2D': Transolver_Structured_Mesh_2D,
-    }
-    if args.model in _OUT_OF_SCOPE:
-        raise KeyError(f"{args.model}: not part of the MI355X-native hot path (see DESIGN.md, out of scope)")
-    return model_dict[args.model]
+    name = args.model
+    if name in NOT_BUILT:
+        raise KeyError(f"{name}: not part of the MI355X-native build (DESIGN.md §7)")
+    return REGISTRY[name]     # KeyError for unknown names, like the reference's dict lookup
