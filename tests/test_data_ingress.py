@@ -1,0 +1,65 @@
+"""CPU: SURVEY 8(f)-4 data ingress — `.mat` slicing conventions of exp_ns.py:64-99 / exp_darcy.py:76-99,
+HBM-resident batching, and invariants of the torch.fft NS generator (parity unpinned, see data.py)."""
+import numpy as np
+import pytest
+import scipy.io as scio
+import torch
+
+from transformerbasednavierstokesolver_amd import data, synth
+
+
+def test_ns_mat_slicing_matches_exp_ns_recipe(tmp_path):
+    u = synth.synth_ns_fields(7, 64, 64, 20, seed=1)
+    path = str(tmp_path / "ns.mat")
+    scio.savemat(path, {"u": u})
+    for r in (1, 2):
+        d = data.load_ns_mat(path, ntrain=4, ntest=2, T_in=10, T=10, r=r)
+        h = int(((64 - 1) / r) + 1)
+        assert d["h"] == h
+        want_a = u[:4, ::r, ::r, :10][:, :h, :h, :].reshape(4, -1, 10)
+        want_u = u[-2:, ::r, ::r, 10:20][:, :h, :h, :].reshape(2, -1, 10)
+        assert np.array_equal(d["train_a"].numpy(), want_a) and np.array_equal(d["test_u"].numpy(), want_u)
+        assert d["train_u"].shape == (4, h * h, 10) and d["test_a"].shape == (2, h * h, 10)
+    pos = data.grid_positions(64)
+    assert pos.shape == (1, 4096, 2) and np.array_equal(pos[0].numpy(), synth.meshgrid_pos(1, 64, 64)[0])
+
+
+def test_darcy_mat_split_and_normalisers(tmp_path):
+    rng = np.random.default_rng(2)
+    mk = lambda n: {"coeff": rng.choice([3.0, 12.0], size=(n, 21, 21)), "sol": rng.standard_normal((n, 21, 21)) * 0.01}
+    ptr, pte = str(tmp_path / "tr.mat"), str(tmp_path / "te.mat")
+    tr, te = mk(6), mk(3)
+    scio.savemat(ptr, tr)
+    scio.savemat(pte, te)
+    d = data.load_darcy_mat(ptr, pte, ntrain=5, ntest=3, r=5)
+    assert d["s"] == 5 and abs(d["dx"] - 0.2) < 1e-15
+    raw = torch.from_numpy(tr["coeff"][:5, ::5, ::5][:, :5, :5].reshape(5, -1)).float()
+    assert torch.allclose(d["x_normalizer"].decode(d["x_train"]), raw, atol=1e-5)
+    assert torch.allclose(d["y_normalizer"].decode(d["y_train"]).double(),
+                          torch.from_numpy(tr["sol"][:5, ::5, ::5][:, :5, :5].reshape(5, -1)), atol=1e-9)
+    assert d["y_test"].shape == (3, 25)          # test targets stay un-normalised (exp_darcy.py:96-97)
+
+
+def test_resident_dataset_batches_and_shards():
+    a, b = torch.arange(10.0).reshape(10, 1), torch.arange(10).reshape(10, 1) * 2
+    ds = data.ResidentDataset(a, b)
+    seen = torch.cat([x for x, _ in ds.batches(4, shuffle=True, generator=torch.Generator().manual_seed(0))])
+    assert sorted(seen.flatten().tolist()) == list(range(10))
+    assert [x.shape[0] for x, _ in ds.batches(4)] == [4, 4, 2]
+    assert [x.shape[0] for x, _ in ds.batches(4, drop_last=True)] == [4, 4]
+    sh = ds.shard(1, 3)
+    assert len(sh) == 3 and sh.tensors[0].flatten().tolist() == [3.0, 4.0, 5.0]
+    with pytest.raises(ValueError):
+        data.ResidentDataset(a, b[:3])
+
+
+def test_ns_generator_invariants():
+    g = torch.Generator().manual_seed(0)
+    w0 = torch.from_numpy(synth.synth_ns_fields(2, 32, 32, 1, seed=3)[..., 0])
+    out = data.simulate_ns_vorticity(w0, visc=1e-3, T=0.2, dt=1e-3, record=4, forcing=False)
+    assert out.shape == (2, 32, 32, 4) and torch.isfinite(out).all()
+    ens = out.double().square().mean(dim=(1, 2))                  # enstrophy decays without forcing
+    assert torch.all(ens[:, 1:] < ens[:, :-1]) and torch.all(ens[:, 0] < w0.double().square().mean(dim=(1, 2)))
+    assert torch.allclose(out.double().mean(dim=(1, 2)), w0.double().mean(dim=(1, 2))[:, None].expand(2, 4), atol=1e-6)
+    again = data.simulate_ns_vorticity(w0, visc=1e-3, T=0.2, dt=1e-3, record=4, forcing=False)
+    assert torch.equal(out, again)
