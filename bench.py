@@ -225,20 +225,29 @@ def main():
         "roofline": roof,
     }
 
-    if rank == 0 and not args.no_rollout:
-        # unrolled-inference steps/s (ns_vorticity_unrolling.py:264-286), hipGraph-captured step
+    if not args.no_rollout:
+        # unrolled-inference steps/s (ns_vorticity_unrolling.py:264-286), hipGraph-captured step.  Replicas
+        # only: every rank rolls out its own trajectories, no communication; the aggregate is
+        # N * batch * 20 frames / (max over ranks of the time of 20 steps).
         model.eval()
         for bsz, tag in ((B, f"b{B}"), (1, "b1")):
             gr = harness.GraphedRollout(model, x[:bsz], fx[:bsz])
             gr.run(fx[:bsz], 2)
             torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
             t1 = time.perf_counter()
             gr.run(fx[:bsz], 20)
             torch.cuda.synchronize()
             d = time.perf_counter() - t1
-            out[f"rollout_steps_per_s_{tag}"] = round(20 / d, 2)
-            out[f"rollout_frames_per_s_{tag}"] = round(20 * bsz / d, 2)
-            log(f"rollout {tag}: {20 / d:.1f} steps/s")
+            if world > 1:
+                td = torch.tensor([d], device=dev, dtype=torch.float64)
+                dist.all_reduce(td, op=dist.ReduceOp.MAX)
+                d = float(td.item())
+            out[f"rollout_steps_per_s_{tag}"] = round(20 / d, 2)                 # per replica
+            out[f"rollout_frames_per_s_{tag}"] = round(world * 20 * bsz / d, 2)  # aggregate over all replicas
+            if rank == 0:
+                log(f"rollout {tag}: {20 / d:.1f} steps/s per replica, {world * 20 * bsz / d:.0f} frames/s aggregate")
             del gr
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
