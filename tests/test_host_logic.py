@@ -154,6 +154,7 @@ def test_c_abi_exports_every_declared_symbol_with_matching_arity():
 
 
 def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setenv("PA2D_NO_AUTOBUILD", "1")
     monkeypatch.setattr(_lib, "_lib", None)
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libpa2d.so")
     with pytest.raises(_lib.NativeLibraryMissing):

@@ -65,11 +65,28 @@ class NativeLibraryMissing(RuntimeError):
     pass
 
 
+def _try_build():
+    """The shared object is a build artefact (git-ignored).  If it is absent but the toolchain is present
+    (same ROCm image), compile it once in-tree — this builds the native path, it is not a fallback."""
+    import shutil
+    import subprocess
+    csrc = os.path.dirname(LIB_PATH)
+    hipcc = shutil.which("hipcc") or ("/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else None)
+    if hipcc is None or shutil.which("make") is None or os.environ.get("PA2D_NO_AUTOBUILD"):
+        return
+    try:
+        subprocess.run(["make", "-C", csrc, "-j4", f"HIPCC={hipcc}"], check=True, stdout=subprocess.DEVNULL)
+    except Exception:      # the caller raises NativeLibraryMissing with the manual instructions
+        pass
+
+
 def load():
     """Load libpa2d.so once and bind every symbol of include/pa2d.h; raises if anything is missing."""
     global _lib
     if _lib is not None:
         return _lib
+    if not os.path.exists(LIB_PATH):
+        _try_build()
     if not os.path.exists(LIB_PATH):
         raise NativeLibraryMissing(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
