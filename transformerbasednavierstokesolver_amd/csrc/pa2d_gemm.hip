@@ -104,11 +104,13 @@ __device__ __forceinline__ void kc_epilogue(const KCParams& p, f32x16 (&acc)[TM]
 #undef KC_EPI
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool IM2COL>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool IM2COL, int BK = 16>
 __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KCParams p) {
-    constexpr int BK = 16, PITCH = BK + 4;
+    constexpr int PITCH = BK + 4;              // 20 or 36 floats: an odd number of 16-byte slots
+    constexpr int QPR = BK / 4;                // float4 per tile row
+    constexpr int RPP = 256 / QPR;             // tile rows loaded per pass of the 256 threads
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N, TM = WM / 32, TN = WN / 32;
-    constexpr int A_IT = BM / 64, B_IT = BN / 64;
+    constexpr int A_IT = BM / RPP, B_IT = BN / RPP;
     static_assert(WAVES_M * WAVES_N == 4 && TM >= 1 && TN >= 1, "tile");
     __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * PITCH];
     float* const As = smem;
@@ -127,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KCParams p) {
     if (tile_m >= tiles_m || slot / tiles_n >= tmx) return;
 
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-    const int lr = tid >> 2, lq = tid & 3;
+    const int lr = tid / QPR, lq = tid % QPR;
 
     const __amdgpu_buffer_rsrc_t ra_rsrc = make_rsrc(p.A, p.a_bytes);
     const __amdgpu_buffer_rsrc_t rb_rsrc = make_rsrc(p.B, p.b_bytes);
@@ -135,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KCParams p) {
     int a_y[A_IT], a_x[A_IT];
 #pragma unroll
     for (int s = 0; s < A_IT; ++s) {
-        const int gm = tile_m * BM + lr + 64 * s;
+        const int gm = tile_m * BM + lr + RPP * s;
         a_off[s] = gm < p.M ? (unsigned)gm * (unsigned)p.lda * 4u + lq * 16u : OOB_OFF;
         if (IM2COL) {
             const int n = gm % (p.H * p.W);
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KCParams p) {
     }
 #pragma unroll
     for (int s = 0; s < B_IT; ++s) {
-        const int gn = tile_n * BN + lr + 64 * s;
+        const int gn = tile_n * BN + lr + RPP * s;
         b_off[s] = gn < p.N ? (unsigned)gn * (unsigned)p.ldb * 4u + lq * 16u : OOB_OFF;
     }
 
@@ -187,9 +189,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KCParams p) {
 #define KC_STORE(buf_)                                                                                 \
     {                                                                                                  \
         _Pragma("unroll") for (int s = 0; s < A_IT; ++s)                                               \
-            *reinterpret_cast<float4*>(As + (buf_) * BM * PITCH + (lr + 64 * s) * PITCH + lq * 4) = ra[s]; \
+            *reinterpret_cast<float4*>(As + (buf_) * BM * PITCH + (lr + RPP * s) * PITCH + lq * 4) = ra[s]; \
         _Pragma("unroll") for (int s = 0; s < B_IT; ++s)                                               \
-            *reinterpret_cast<float4*>(Bs + (buf_) * BN * PITCH + (lr + 64 * s) * PITCH + lq * 4) = rb[s]; \
+            *reinterpret_cast<float4*>(Bs + (buf_) * BN * PITCH + (lr + RPP * s) * PITCH + lq * 4) = rb[s]; \
     }
 
     KC_LOAD(0)
@@ -469,6 +471,14 @@ static int gemm_mode_split() { return gemm_mode() != 0; }
 // chunk (channels per tap step) the conv weight packs must use for the selected engine
 // the experimental split engine is only used for the conv implicit GEMMs (it is slower than the f32
 // engine on the short-K linears)
+// K-step of the big fp32 tiles: 32 by default (half the barriers, full 128-byte row segments, 72 KB of LDS
+// -> 2 workgroups per CU; measured 3-4 % faster than 16 with 4 workgroups per CU: conv 2.61 -> 2.52 ms);
+// PA2D_KC_BK=16 forces the 16-wide step.
+static bool kc_bk32(bool im2col, int Cin) {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("PA2D_KC_BK"); v = (e && atoi(e) == 16) ? 0 : 1; }
+    return v && (!im2col || (Cin % 32) == 0);
+}
 static bool use_split(int N, bool im2col, int Cin) {
     const int m = gemm_mode();
     if (m == 1) return im2col && N > 64 && (Cin % 32) == 0;
@@ -527,7 +537,10 @@ static int launch_kc(const KCParams& p_in, bool im2col, hipStream_t st, hipEvent
         if (p.N > 64 && t128 >= 384) {
             const int tiles_n = ceil_div(p.N, 128);
             const dim3 grid(ceil_div(tiles_m, 8) * 8 * tiles_n);
-            if (im2col) hipLaunchKernelGGL((gemm_kc_kernel<128, 128, 2, 2, true>), grid, dim3(256), 0, st, p);
+            if (kc_bk32(im2col, p.Cin)) {
+                if (im2col) hipLaunchKernelGGL((gemm_kc_kernel<128, 128, 2, 2, true, 32>), grid, dim3(256), 0, st, p);
+                else hipLaunchKernelGGL((gemm_kc_kernel<128, 128, 2, 2, false, 32>), grid, dim3(256), 0, st, p);
+            } else if (im2col) hipLaunchKernelGGL((gemm_kc_kernel<128, 128, 2, 2, true>), grid, dim3(256), 0, st, p);
             else hipLaunchKernelGGL((gemm_kc_kernel<128, 128, 2, 2, false>), grid, dim3(256), 0, st, p);
         } else if (t12864 >= 384 || p.M <= 64) {
             const int tiles_n = ceil_div(p.N, 64);
@@ -559,9 +572,8 @@ struct MCParams {
 // BF16 = true: same staging (fp32 tiles [16 rows m][BM]), but each lane gathers its 8 consecutive m of
 // one column with 8 ds_read_b32, rounds them to bf16 and issues ONE v_mfma_f32_32x32x16_bf16 per tile
 // and 16-row chunk instead of 8 fp32 MFMAs (bf16-compute mode).
-template <int BM, int BN, bool IM2COL, bool BF16>
+template <int BM, int BN, bool IM2COL, bool BF16, int BK = 16>
 __global__ __launch_bounds__(256, 2) void gemm_mc_kernel(const MCParams p) {
-    constexpr int BK = 16;
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int A_TPR = BM / 4, A_RPP = 256 / A_TPR, A_IT = BK / A_RPP;
     constexpr int B_TPR = BN / 4, B_RPP = 256 / B_TPR, B_IT = BK / B_RPP;
@@ -592,9 +604,11 @@ __global__ __launch_bounds__(256, 2) void gemm_mc_kernel(const MCParams p) {
     }
     const int wm = wave >> 1, wn = wave & 1;
 
+    // the host plans in 16-row chunks; a K-step of BK rows covers BK/16 of them
     const int total_chunks = (p.Mk + BK - 1) / BK;
-    const int c_begin = split * p.chunks_per_split;
-    const int c_end = min(total_chunks, c_begin + p.chunks_per_split);
+    const int cps = (p.chunks_per_split * 16 + BK - 1) / BK;
+    const int c_begin = split * cps;
+    const int c_end = min(total_chunks, c_begin + cps);
 
     const int a_r = tid / A_TPR, a_c = (tid % A_TPR) * 4;
     const int b_r = tid / B_TPR, b_c = (tid % B_TPR) * 4;
@@ -824,7 +838,12 @@ static int launch_mc(const float* A, long long lda, int Mi, const float* B, long
     const int bm = pl.big ? 128 : 64;
     const dim3 grid(ceil_div(Mi, bm) * ceil_div(Nj, bm) * pl.splits);
     const bool bf = gemm_mode() == 2;
-    if (pl.big && bf) {
+    static int mc_bk = -1;
+    if (mc_bk < 0) { const char* e = getenv("PA2D_MC_BK"); mc_bk = (e && atoi(e) == 32) ? 32 : 16; }
+    if (pl.big && !bf && mc_bk == 32 && (pl.chunks_per_split % 2) == 0) {
+        if (im2col) hipLaunchKernelGGL((gemm_mc_kernel<128, 128, true, false, 32>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_mc_kernel<128, 128, false, false, 32>), grid, dim3(256), 0, st, p);
+    } else if (pl.big && bf) {
         if (im2col) hipLaunchKernelGGL((gemm_mc_kernel<128, 128, true, true>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((gemm_mc_kernel<128, 128, false, true>), grid, dim3(256), 0, st, p);
     } else if (pl.big) {
@@ -1039,7 +1058,7 @@ int pa2d_conv3x3x2_fwd(const float* xn, const float* wx, const float* bx, const 
                            wx, wf, (__bf16*)pack, 0, gemm_mode() == 2 ? 1 : 3, C, C);
         PA2D_CHECK_LAUNCH();
     } else {
-        rc = launch_repack(wx, wf, pack, 1, 0, 16, C, C, st);
+        rc = launch_repack(wx, wf, pack, 1, 0, (kc_bk32(true, C) && (long long)ceil_div(B * H * W, 128) * ceil_div(2 * C, 128) >= 384 && 2 * C > 64) ? 32 : 16, C, C, st);
         if (rc) return rc;
     }
     hipError_t e = hipMemcpyAsync(bias2_ws, bx, C * sizeof(float), hipMemcpyDeviceToDevice, st);
@@ -1068,7 +1087,7 @@ int pa2d_conv3x3x2_bwd(const float* dout, const float* xn, const float* wx, cons
                                st, wx, wf, (__bf16*)pack, 1, gemm_mode() == 2 ? 1 : 3, C, C);
             PA2D_CHECK_LAUNCH();
         } else {
-            rc = launch_repack(wx, wf, pack, 2, 0, 16, C, C, st);
+            rc = launch_repack(wx, wf, pack, 2, 0, (kc_bk32(true, 2 * C) && (long long)ceil_div(M, 128) * ceil_div(C, 128) >= 384 && C > 64) ? 32 : 16, C, C, st);
             if (rc) return rc;
         }
         KCParams p = {};
