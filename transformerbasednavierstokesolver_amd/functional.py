@@ -158,6 +158,62 @@ class HeadFn(Function):
         return dxn.view(ctx.shp), dw, db
 
 
+class AttnBranchFn(Function):
+    """fx + Attn(LayerNorm(fx)) as ONE autograd node (Transolver_block.forward, …_2D.py:70): the residual
+    gradient is folded into the LayerNorm backward kernel (`dres`), so no separate elementwise add runs."""
+
+    @staticmethod
+    def forward(ctx, fx, ln_w, ln_b, H, W, heads, *params):
+        shp = fx.shape
+        fx2d = fx.detach().reshape(-1, shp[-1]).contiguous()
+        ln_w, ln_b = ln_w.detach().contiguous(), ln_b.detach().contiguous()
+        xn, mean, rstd = ops.layernorm_fwd(fx2d, ln_w, ln_b)
+        P = dict(zip(ATTN_KEYS, (p.detach().contiguous() for p in params)))
+        out, saved = attn_forward(xn.view(shp), P, fx2d.view(shp), H, W, heads)
+        ctx.P, ctx.saved, ctx.geom, ctx.ln = P, saved, (H, W, heads), (fx2d, mean, rstd, ln_w)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        H, W, heads = ctx.geom
+        fx2d, mean, rstd, ln_w = ctx.ln
+        dout = dout.contiguous()
+        dxn, g = attn_backward(ctx.saved, ctx.P, dout, H, W, heads, need_dx=True)
+        dfx, dg, db = ops.layernorm_bwd(dxn.reshape(fx2d.shape), fx2d, mean, rstd, ln_w, dres=dout.reshape(fx2d.shape))
+        return (dfx.view(dout.shape), dg, db, None, None, None) + tuple(g[k] for k in ATTN_KEYS)
+
+
+class MLPBranchFn(Function):
+    """fx + MLP(LayerNorm(fx)) as one autograd node (…_2D.py:71), residual gradient folded into LN backward."""
+
+    @staticmethod
+    def forward(ctx, fx, ln_w, ln_b, act, w1, b1, w2, b2):
+        shp = fx.shape
+        fx2d = fx.detach().reshape(-1, shp[-1]).contiguous()
+        ln_w, ln_b, w1, b1, w2, b2 = (t.detach().contiguous() for t in (ln_w, ln_b, w1, b1, w2, b2))
+        xn, mean, rstd = ops.layernorm_fwd(fx2d, ln_w, ln_b)
+        out, saved = mlp_forward(xn, w1, b1, w2, b2, act, fx2d)
+        ctx.saved, ctx.w, ctx.act, ctx.ln = saved, (w1, w2), act, (fx2d, mean, rstd, ln_w)
+        return out.view(shp)
+
+    @staticmethod
+    def backward(ctx, dout):
+        w1, w2 = ctx.w
+        fx2d, mean, rstd, ln_w = ctx.ln
+        d2 = dout.reshape(fx2d.shape).contiguous()
+        dxn, dw1, db1, dw2, db2 = mlp_backward(ctx.saved, w1, w2, ctx.act, d2, need_dx=True)
+        dfx, dg, db = ops.layernorm_bwd(dxn, fx2d, mean, rstd, ln_w, dres=d2)
+        return dfx.view(dout.shape), dg, db, None, dw1, db1, dw2, db2
+
+
+def attn_branch(fx, ln_w, ln_b, H, W, heads, params):
+    return AttnBranchFn.apply(fx, ln_w, ln_b, H, W, heads, *params)
+
+
+def mlp_branch(fx, ln_w, ln_b, act, w1, b1, w2, b2):
+    return MLPBranchFn.apply(fx, ln_w, ln_b, act, w1, b1, w2, b2)
+
+
 class LinearFn(Function):
     """y = act(x . w^T + b): generic dense layer (MLP hidden layers when n_layers > 0, wide heads)."""
 

@@ -40,7 +40,7 @@ class Physics_Attention_Structured_Mesh_2D(nn.Module):
         self.to_v = nn.Linear(dim_head, dim_head, bias=False)
         self.to_out = nn.Sequential(nn.Linear(inner_dim, dim), nn.Dropout(dropout))
 
-    def _params(self):
+    def attention_parameters(self):
         return (self.temperature, self.in_project_x.weight, self.in_project_x.bias, self.in_project_fx.weight,
                 self.in_project_fx.bias, self.in_project_slice.weight, self.in_project_slice.bias,
                 self.to_q.weight, self.to_k.weight, self.to_v.weight, self.to_out[0].weight, self.to_out[0].bias)
@@ -53,4 +53,4 @@ class Physics_Attention_Structured_Mesh_2D(nn.Module):
         B, N, C = x.shape
         if N != self.H * self.W:
             raise RuntimeError(f"shape '[{B}, {self.H}, {self.W}, {C}]' is invalid for input of size {x.numel()}")
-        return Fn.physics_attention(x, residual, self.H, self.W, self.heads, self._params())
+        return Fn.physics_attention(x, residual, self.H, self.W, self.heads, self.attention_parameters())

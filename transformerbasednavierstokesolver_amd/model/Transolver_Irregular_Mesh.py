@@ -26,13 +26,15 @@ class Physics_Attention_Irregular_Mesh(nn.Module):
         self.to_q, self.to_k, self.to_v = (nn.Linear(dim_head, dim_head, bias=False) for _ in range(3))
         self.to_out = nn.Sequential(nn.Linear(dim, dim), nn.Dropout(dropout))
 
+    def attention_parameters(self):
+        return (self.temperature, self.in_project_x.weight, self.in_project_x.bias, self.in_project_fx.weight,
+                self.in_project_fx.bias, self.in_project_slice.weight, self.in_project_slice.bias,
+                self.to_q.weight, self.to_k.weight, self.to_v.weight, self.to_out[0].weight, self.to_out[0].bias)
+
     def forward(self, x, residual=None):
         if self.training and self.dropout.p > 0:
             raise NotImplementedError("dropout > 0 is not implemented in the HIP path; refusing to ignore it")
-        params = (self.temperature, self.in_project_x.weight, self.in_project_x.bias, self.in_project_fx.weight,
-                  self.in_project_fx.bias, self.in_project_slice.weight, self.in_project_slice.bias,
-                  self.to_q.weight, self.to_k.weight, self.to_v.weight, self.to_out[0].weight, self.to_out[0].bias)
-        return Fn.physics_attention(x, residual, None, None, self.heads, params)   # H=W=None -> irregular variant
+        return Fn.physics_attention(x, residual, None, None, self.heads, self.attention_parameters())   # H=W=None -> irregular
 
 
 class Transolver_block(BlockBase):

@@ -69,8 +69,18 @@ class BlockBase(nn.Module):
             self.mlp2 = nn.Linear(hidden_dim, out_dim)
 
     def forward(self, fx):
-        fx = self.Attn(Fn.layer_norm(fx, self.ln_1.weight, self.ln_1.bias), residual=fx)
-        fx = self.mlp(Fn.layer_norm(fx, self.ln_2.weight, self.ln_2.bias), residual=fx)
+        attn, mlp = self.Attn, self.mlp
+        if attn.training and attn.dropout.p > 0:
+            raise NotImplementedError("dropout > 0 is not implemented in the HIP path; refusing to ignore it")
+        # each residual branch (LayerNorm -> sub-layer -> + fx) is one autograd node
+        fx = Fn.attn_branch(fx, self.ln_1.weight, self.ln_1.bias, getattr(attn, "H", None), getattr(attn, "W", None),
+                            attn.heads, attn.attention_parameters())
+        pre, post = mlp.linear_pre[0], mlp.linear_post
+        if mlp.linears or pre.weight.shape[1] % 4:      # generic MLP shapes keep the unfused route
+            fx = mlp(Fn.layer_norm(fx, self.ln_2.weight, self.ln_2.bias), residual=fx)
+        else:
+            fx = Fn.mlp_branch(fx, self.ln_2.weight, self.ln_2.bias, mlp.act_name, pre.weight, pre.bias,
+                               post.weight, post.bias)
         if not self.last_layer:
             return fx
         z = Fn.layer_norm(fx, self.ln_3.weight, self.ln_3.bias)
