@@ -285,3 +285,38 @@ def test_g6_irregular_mesh_model(tag):
         assert rel_l2(_sample(p.grad, 65), g[f"{tag}.grad.sample.{k}"]) < tol, k
         ref = float(g[f"{tag}.grad.norm.{k}"])
         assert abs(float(p.grad.double().norm()) - ref) < tol * ref, k
+
+
+def test_full_bench_batch_consistency_and_determinism():
+    """Size-independent properties at the BASELINE configs[1] batch (B=32, 64x64, C=256, M=64; 2 layers to
+    keep it short): (1) the batch is a set of independent trajectories — outputs of the B=32 call equal the
+    per-sample calls and the batch-summed-loss gradient equals the sum of per-sample gradients (different
+    tile shapes are used for B=1, so equality is to fp32 rounding, not bitwise); (2) no float atomics
+    anywhere: two identical runs give bitwise identical outputs and gradients."""
+    from transformerbasednavierstokesolver_amd import synth, harness
+    from transformerbasednavierstokesolver_amd.utils.testloss import TestLoss
+    cfg = dict(synth.NS_CONFIG, n_layers=2)
+    m = harness.build_model(cfg, synth.synth_state_dict(cfg, seed=131), DEV)
+    pos, a, u = synth.ns_batch(32, seed=132)
+    x, fx, y = (torch.from_numpy(t).to(DEV) for t in (pos, a, u[..., :1]))
+    loss_fn = TestLoss(size_average=False)
+
+    def run(xs, fs, ys):
+        m.zero_grad(set_to_none=True)
+        pred = m(xs, fx=fs)
+        loss_fn(pred.reshape(xs.shape[0], -1), ys.reshape(xs.shape[0], -1)).backward()
+        return pred.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters() if p.grad is not None}
+
+    p1, g1 = run(x, fx, y)
+    p2, g2 = run(x, fx, y)
+    assert torch.equal(p1, p2) and all(torch.equal(g1[k], g2[k]) for k in g1), "run-to-run results must be bitwise identical"
+    acc = None
+    for i in (0, 13, 31):
+        pi, gi = run(x[i:i + 1], fx[i:i + 1], y[i:i + 1])
+        assert rel_l2(pi, p1[i:i + 1]) < 1e-5, i      # fp32 forward tolerance (SURVEY 8c)
+    # gradient additivity over a split of the batch into 4 shards of 8 (what DDP relies on)
+    for s in range(4):
+        _, gs = run(x[8 * s:8 * s + 8], fx[8 * s:8 * s + 8], y[8 * s:8 * s + 8])
+        acc = gs if acc is None else {k: acc[k] + gs[k] for k in acc}
+    for k in g1:
+        assert rel_l2(acc[k], g1[k]) < (2e-3 if ("to_q" in k or "to_k" in k) else 1e-4), k
