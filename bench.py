@@ -109,6 +109,8 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-rollout", action="store_true")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay forward+backward from one hipGraph (launch-bound small batches); disables the per-kernel HIP events")
     ap.add_argument("--torch-optim", action="store_true", help="torch.optim.AdamW + torch rel-L2 instead of the fused kernels")
     ap.add_argument("--gemm-mode", type=int, default=0,
                     help="0 = exact fp32 MFMA (the metric of record), 2 = bf16-compute mode (BASELINE configs[2] numerics)")
@@ -164,7 +166,13 @@ def main():
     pool = HipEventPool(args.steps * layers * calls * 2 + 8)
     ops.conv_event_provider = pool.provider
 
+    if args.graph:
+        ops.conv_event_provider = None
+        graphed = harness.GraphedTrainStep(model, opt, sched, x, fx, yy, loss_fn=loss_fn)
+
     def step():
+        if args.graph:
+            return graphed(x, fx, yy)
         return harness.train_step(model, opt, sched, x, fx, yy, grad_sync=sync, loss_fn=loss_fn)
 
     for i in range(args.warmup):
@@ -219,7 +227,8 @@ def main():
                                "backward + AdamW/OneCycleLR): Transolver_Structured_Mesh_2D 8 layers, C=256, 8 heads, "
                                f"M=64 slices, fp32, batch {B}/GPU (BASELINE configs[1])",
                    "global_batch": world * B, "batch_per_gpu": B, "parallelism": f"dp{world}",
-                   "model_calls_per_step": calls, "grad_allreduce_bytes": sync.nbytes},
+                   "model_calls_per_step": calls, "grad_allreduce_bytes": sync.nbytes,
+                   "hipgraph_training_step": bool(args.graph)},
         "model_call_samples_per_s": round(world * B * args.steps * calls / dt, 2),
         "final_loss_per_sample_call": round(float(loss) / B / calls, 5),
         "roofline": roof,

@@ -121,6 +121,57 @@ class GraphedRollout:
         return torch.cat(frames, -1)
 
 
+class GraphedTrainStep:
+    """exp_ns iteration with the launch-bound part captured in ONE hipGraph.
+
+    At the reference's batch sizes (2-8) an iteration is ~14 000 kernel launches and the host cannot
+    issue them as fast as the GPU retires them.  Captured once, replayed per iteration: zeroing the flat
+    gradient bucket, the T/step teacher-forced model calls, the summed rel-L2 loss and the whole backward
+    pass (static input buffers; every intermediate lives in the graph's private pool).  The gradient
+    all-reduce, `optimizer.step()` and `scheduler.step()` stay eager because the OneCycle lr / beta1 are
+    host scalars that change every iteration (2-3 launches).  Needs `optim.FusedAdamW` (gradients must be
+    views of one persistent flat buffer).  Replays run the same kernels in the same order as the eager
+    path, so results are bit-identical to `train_step`."""
+
+    def __init__(self, model, optimizer, scheduler, x, fx, yy, step=1, loss_fn=None, warmup=3):
+        from .optim import FusedAdamW
+        if not isinstance(optimizer, FusedAdamW):
+            raise TypeError("GraphedTrainStep needs optim.FusedAdamW (persistent flat gradient bucket)")
+        self.model, self.opt, self.sched, self.step_size, self.loss_fn = model, optimizer, scheduler, step, loss_fn
+        self.x, self.fx, self.yy = x.clone(), fx.clone(), yy.clone()
+        snap = [p.detach().clone() for p in model.parameters()]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):           # builds the flat buffers, sets kernel attributes, warms the allocator
+                self._fwd_bwd()
+                if optimizer.flat_p is None:
+                    optimizer._build()
+        torch.cuda.current_stream().wait_stream(side)
+        for p, q in zip(model.parameters(), snap):     # warm-up must not move the weights
+            p.data.copy_(q)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss, self.full = self._fwd_bwd()
+
+    def _fwd_bwd(self):
+        self.opt.zero_grad()
+        loss, full, _ = train_iteration(self.model, self.x, self.fx, self.yy, self.step_size, self.loss_fn)
+        loss.backward()
+        return loss.detach(), full
+
+    def __call__(self, x, fx, yy):
+        self.x.copy_(x)
+        self.fx.copy_(fx)
+        self.yy.copy_(yy)
+        self.graph.replay()
+        self.opt.sync()                 # all-reduce(SUM) of the flat bucket when world_size > 1
+        self.opt.step()
+        if self.sched is not None:
+            self.sched.step()
+        return self.loss, self.full
+
+
 # ------------------------------------------------------------------------------ unrolled look-ahead training
 def unrolled_train_iteration(sol_model, x, fx, yy, look_ahead, step=1, loss_fn=None):
     """One mini-batch of ns_vorticity_unrolling.py:225-244.  `sol_model.n` chained calls per window;
