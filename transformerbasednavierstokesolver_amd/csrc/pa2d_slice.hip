@@ -675,9 +675,13 @@ extern "C" {
 
 // number of point chunks per (batch, head) and points per chunk used by every slice-stage kernel
 int pa2d_slice_nchunk(int B, int N, int heads) {
+    // enough chunks to fill the CUs at small batch, but at most 16: the token kernel sums the chunk
+    // partials serially per element (64 chunks made it 3x slower than the attention itself at B=2), and
+    // at least 256 points per workgroup keep 4 groups per wave in flight
     const int bh = B * heads;
     int nchunk = ceil_div(1024, bh);
-    const int maxc = ceil_div(N, 64);
+    int maxc = ceil_div(N, 256);
+    if (maxc > 16) maxc = 16;
     if (nchunk > maxc) nchunk = maxc;
     if (nchunk < 1) nchunk = 1;
     int ppc = ceil_div(ceil_div(N, nchunk), 16) * 16;

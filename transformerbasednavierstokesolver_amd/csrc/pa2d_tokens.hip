@@ -9,6 +9,20 @@
 
 int pa2d_launch_reduce(const float* slab, int nslab, long long count, float* out, hipStream_t st);
 
+// sum of the per-chunk partials of one element, 4 loads in flight, fixed order (deterministic)
+__device__ __forceinline__ float sum_chunks(const float* __restrict__ base, int nchunk, size_t stride) {
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int c = 0;
+    for (; c + 3 < nchunk; c += 4) {
+        s0 += base[(size_t)c * stride];
+        s1 += base[(size_t)(c + 1) * stride];
+        s2 += base[(size_t)(c + 2) * stride];
+        s3 += base[(size_t)(c + 3) * stride];
+    }
+    for (; c < nchunk; ++c) s0 += base[(size_t)c * stride];
+    return (s0 + s1) + (s2 + s3);
+}
+
 struct TokParams {
     const float* spart; const float* npart;   // [B*heads, nchunk, M, D], [B*heads, nchunk, M]
     const float* wq; const float* wk; const float* wv;   // [D, D] (out, in), shared by all heads
@@ -83,15 +97,13 @@ __global__ __launch_bounds__(256) void token_attn_fwd_kernel(const TokParams p) 
         l.Wq[e * l.P + d] = p.wq[i]; l.Wk[e * l.P + d] = p.wk[i]; l.Wv[e * l.P + d] = p.wv[i];
     }
     for (int m = tid; m < M; m += 256) {
-        float s = 0.f;
-        for (int c = 0; c < p.nchunk; ++c) s += p.npart[(bh * p.nchunk + c) * M + m];
+        const float s = sum_chunks(p.npart + bh * p.nchunk * M + m, p.nchunk, M);
         l.nr[m] = s;
         p.nrm[bh * M + m] = s;
     }
     __syncthreads();
     for (int i = tid; i < M * D; i += 256) {
-        float s = 0.f;
-        for (int c = 0; c < p.nchunk; ++c) s += p.spart[(bh * p.nchunk + c) * M * D + i];
+        const float s = sum_chunks(p.spart + bh * p.nchunk * M * D + i, p.nchunk, (size_t)M * D);
         p.s[bh * M * D + i] = s;
         l.T[(i / D) * l.P + (i % D)] = s / (l.nr[i / D] + SLICE_EPS);
     }
@@ -133,9 +145,7 @@ __global__ __launch_bounds__(256) void token_attn_bwd_kernel(const TokBwdParams 
     for (int i = tid; i < M * D; i += 256) {
         const int m = i / D, d = i % D;
         l.T[m * P + d] = p.s[bh * M * D + i] / (l.nr[m] + SLICE_EPS);
-        float g = 0.f;
-        for (int c = 0; c < p.nchunk; ++c) g += p.dopart[(bh * p.nchunk + c) * M * D + i];
-        G1[m * P + d] = g;
+        G1[m * P + d] = sum_chunks(p.dopart + bh * p.nchunk * M * D + i, p.nchunk, (size_t)M * D);
     }
     __syncthreads();
     tokens_forward_core(l, M, D, tid);
