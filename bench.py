@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--no-rollout", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="replay forward+backward from one hipGraph (launch-bound small batches); disables the per-kernel HIP events")
+    ap.add_argument("--fold-time", action="store_true",
+                    help="run the 10 teacher-forced calls of an iteration as ONE call on 10*B windows (same loss and gradients)")
+    ap.add_argument("--no-folded-leg", action="store_true", help="skip the secondary time-folded measurement")
     ap.add_argument("--torch-optim", action="store_true", help="torch.optim.AdamW + torch rel-L2 instead of the fused kernels")
     ap.add_argument("--gemm-mode", type=int, default=0,
                     help="0 = exact fp32 MFMA (the metric of record), 2 = bf16-compute mode (BASELINE configs[2] numerics)")
@@ -149,7 +152,7 @@ def main():
     else:   # fused multi-tensor AdamW + fused rel-L2 (libpa2d), same arithmetic
         opt = FusedAdamW(model.parameters(), lr=1e-3, weight_decay=1e-5)
         loss_fn = FusedTestLoss(size_average=False)
-    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-3, total_steps=max(total_steps, 2) + 1)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-3, total_steps=2 * max(total_steps, 2) + 4)
     log(f"rank {rank}/{world}: model built, generating {B} synthetic trajectories")
     pos, a, u = synth.ns_batch(B, seed=100 + rank)    # this rank's shard of the global batch
     x, fx, yy = (torch.from_numpy(t).to(dev) for t in (pos, a, u))
@@ -168,12 +171,12 @@ def main():
 
     if args.graph:
         ops.conv_event_provider = None
-        graphed = harness.GraphedTrainStep(model, opt, sched, x, fx, yy, loss_fn=loss_fn)
+        graphed = harness.GraphedTrainStep(model, opt, sched, x, fx, yy, loss_fn=loss_fn, fold_time=args.fold_time)
 
     def step():
         if args.graph:
             return graphed(x, fx, yy)
-        return harness.train_step(model, opt, sched, x, fx, yy, grad_sync=sync, loss_fn=loss_fn)
+        return harness.train_step(model, opt, sched, x, fx, yy, grad_sync=sync, loss_fn=loss_fn, fold_time=args.fold_time)
 
     for i in range(args.warmup):
         step()
@@ -202,14 +205,14 @@ def main():
     conv_ms = pool.durations_ms()
     N = cfg["H"] * cfg["W"]
     C = cfg["n_hidden"]
-    conv_flops = 2.0 * (B * N) * (9 * C) * (2 * C)
+    conv_flops = 2.0 * (B * (calls if args.fold_time else 1) * N) * (9 * C) * (2 * C)
     roof = None
     if conv_ms:
         avg_ms = float(np.mean(conv_ms))
         achieved = conv_flops / (avg_ms * 1e-3) / 1e12
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "conv_pmc_traffic.json")
-        if os.path.exists(pmc):
+        if os.path.exists(pmc) and B == 32 and not args.fold_time and args.gemm_mode == 0:   # measured on that launch shape
             try:
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             except Exception:
@@ -228,11 +231,37 @@ def main():
                                f"M=64 slices, fp32, batch {B}/GPU (BASELINE configs[1])",
                    "global_batch": world * B, "batch_per_gpu": B, "parallelism": f"dp{world}",
                    "model_calls_per_step": calls, "grad_allreduce_bytes": sync.nbytes,
-                   "hipgraph_training_step": bool(args.graph)},
+                   "hipgraph_training_step": bool(args.graph), "time_folded_calls": bool(args.fold_time)},
         "model_call_samples_per_s": round(world * B * args.steps * calls / dt, 2),
         "final_loss_per_sample_call": round(float(loss) / B / calls, 5),
         "roofline": roof,
     }
+
+    if not (args.fold_time or args.graph or args.no_folded_leg):
+        # Secondary leg, reported next to (never instead of) `value`: the same iteration with its teacher-forced
+        # calls folded into one call on calls*B windows (harness.train_iteration(fold_time=True); identical
+        # loss/gradients, tests/test_gpu_optim.py).  Needs the driver loop changed, so it is not the drop-in number.
+        def fstep():
+            return harness.train_step(model, opt, sched, x, fx, yy, grad_sync=sync, loss_fn=loss_fn, fold_time=True)
+        fstep()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            fstep()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        fd = time.perf_counter() - t1
+        if world > 1:
+            tf_ = torch.tensor([fd], device=dev, dtype=torch.float64)
+            dist.all_reduce(tf_, op=dist.ReduceOp.MAX)
+            fd = float(tf_.item())
+        out["time_folded"] = {"value": round(world * B * args.steps / fd, 4), "unit": "samples/s",
+                              "ms_per_step": round(1e3 * fd / args.steps, 2),
+                              "note": "10 teacher-forced calls run as one call on 10*B windows (caller-side change)"}
+        log(f"time-folded leg: {out['time_folded']['value']} samples/s")
 
     if not args.no_rollout:
         # unrolled-inference steps/s (ns_vorticity_unrolling.py:264-286), hipGraph-captured step.  Replicas

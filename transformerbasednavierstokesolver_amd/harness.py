@@ -33,11 +33,20 @@ def build_model(cfg, state_dict=None, device="cuda"):
     return m.to(device)
 
 
-def train_iteration(model, x, fx, yy, step=1, loss_fn=None):
-    """Forward part of one exp_ns mini-batch.  Returns (loss [graph attached], full_loss, pred)."""
+def train_iteration(model, x, fx, yy, step=1, loss_fn=None, fold_time=False):
+    """Forward part of one exp_ns mini-batch.  Returns (loss [graph attached], full_loss, pred).
+
+    `fold_time`: the loop below is teacher-forced — the input window of call t is built from GROUND
+    TRUTH frames only (exp_ns.py:205), so the T/step model calls do not depend on each other.  Folded,
+    they run as ONE call on a batch of (T/step)*B windows: the same per-window outputs, the same summed
+    loss and (up to fp32 summation order inside the weight-gradient reductions) the same gradients, with
+    1/(T/step) of the launches, no per-call gradient accumulation and full tiles at the reference's small
+    batch sizes.  Not applicable to the prediction-feedback rollout."""
     loss_fn = loss_fn or TestLoss(size_average=False)
     T = yy.shape[-1]
     bsz = x.shape[0]
+    if fold_time:
+        return _train_iteration_folded(model, x, fx, yy, step, loss_fn)
     loss = 0
     preds = []
     for t in range(0, T, step):
@@ -52,13 +61,30 @@ def train_iteration(model, x, fx, yy, step=1, loss_fn=None):
     return loss, full, pred
 
 
+def _train_iteration_folded(model, x, fx, yy, step, loss_fn):
+    T, bsz, F = yy.shape[-1], x.shape[0], fx.shape[-1]
+    nt = len(range(0, T, step))
+    seq = torch.cat((fx, yy), dim=-1)                                     # frames the windows slide over
+    wins = torch.stack([seq[..., t * step:t * step + F] for t in range(nt)], 0)       # [nt,B,N,F]
+    im = model(x.repeat(nt, 1, 1), fx=wins.reshape(nt * bsz, *fx.shape[1:]))          # [nt*B,N,step]
+    im = im.reshape(nt, bsz, *im.shape[1:])
+    loss = 0
+    for t in range(nt):                       # per-call loss terms, so any reduction mode of loss_fn carries over
+        y = yy[..., t * step:(t + 1) * step]
+        loss = loss + loss_fn(im[t].reshape(bsz, -1), y.reshape(bsz, -1))
+    pred = im.permute(1, 2, 0, 3).reshape(bsz, im.shape[2], -1)
+    with torch.no_grad():
+        full = loss_fn(pred.reshape(bsz, -1), yy.reshape(bsz, -1))
+    return loss, full, pred
+
+
 def train_step(model, optimizer, scheduler, x, fx, yy, step=1, max_grad_norm=None, grad_sync=None,
-               set_to_none=False, loss_fn=None):
+               set_to_none=False, loss_fn=None, fold_time=False):
     """One full exp_ns.py:191-218 iteration.  `grad_sync` (DDP): callable run between backward and
     the optimizer step (all-reduce SUM of the flat gradient bucket).  With `optim.FusedAdamW` pass
     `grad_sync=optimizer.sync` (same bucket) and put the clip threshold in the optimizer instead of
     `max_grad_norm`."""
-    loss, full, _ = train_iteration(model, x, fx, yy, step, loss_fn)
+    loss, full, _ = train_iteration(model, x, fx, yy, step, loss_fn, fold_time)
     optimizer.zero_grad(set_to_none=set_to_none)
     loss.backward()
     if grad_sync is not None:
@@ -133,8 +159,9 @@ class GraphedTrainStep:
     views of one persistent flat buffer).  Replays run the same kernels in the same order as the eager
     path, so results are bit-identical to `train_step`."""
 
-    def __init__(self, model, optimizer, scheduler, x, fx, yy, step=1, loss_fn=None, warmup=3):
+    def __init__(self, model, optimizer, scheduler, x, fx, yy, step=1, loss_fn=None, warmup=3, fold_time=False):
         from .optim import FusedAdamW
+        self.fold_time = fold_time
         if not isinstance(optimizer, FusedAdamW):
             raise TypeError("GraphedTrainStep needs optim.FusedAdamW (persistent flat gradient bucket)")
         self.model, self.opt, self.sched, self.step_size, self.loss_fn = model, optimizer, scheduler, step, loss_fn
@@ -156,7 +183,8 @@ class GraphedTrainStep:
 
     def _fwd_bwd(self):
         self.opt.zero_grad()
-        loss, full, _ = train_iteration(self.model, self.x, self.fx, self.yy, self.step_size, self.loss_fn)
+        loss, full, _ = train_iteration(self.model, self.x, self.fx, self.yy, self.step_size, self.loss_fn,
+                                        self.fold_time)
         loss.backward()
         return loss.detach(), full
 
