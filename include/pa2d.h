@@ -79,13 +79,12 @@ int pa2d_gemm_bwd_weight(const float* dy, long long lddy, const float* x, long l
  * so a benchmark can time that kernel alone without a profiler. */
 size_t pa2d_conv3x3x2_workspace(int B, int H, int W, int C);
 int pa2d_conv3x3x2_fwd(const float* xn, const float* wx, const float* bx, const float* wf, const float* bf,
-                       float* out, float* bias2_ws /* 2C floats */, void* ws, size_t ws_bytes, int B, int H,
-                       int W, int C, pa2d_stream_t stream, void* ev_start, void* ev_stop);
+                       float* out, void* ws, size_t ws_bytes, int B, int H, int W, int C,
+                       pa2d_stream_t stream, void* ev_start, void* ev_stop);
 /* dxn may be NULL (input needs no gradient) */
 int pa2d_conv3x3x2_bwd(const float* dout, const float* xn, const float* wx, const float* wf, float* dxn,
-                       float* dwx, float* dbx, float* dwf, float* dbf, float* dbias2_ws /* 2C floats */,
-                       void* ws, size_t ws_bytes, int B, int H, int W, int C, pa2d_stream_t stream,
-                       void* ev_start, void* ev_stop);
+                       float* dwx, float* dbx, float* dwf, float* dbf, void* ws, size_t ws_bytes, int B, int H,
+                       int W, int C, pa2d_stream_t stream, void* ev_start, void* ev_stop);
 
 /* ---- slice: softmax((x_mid . Ws^T + bs) / clamp(temperature, .1, 5)) and the weighted scatter of
  * N points into M tokens, Physics_Attention.py:98-101.  Emits per-chunk partial sums

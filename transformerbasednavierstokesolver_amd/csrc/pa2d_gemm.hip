@@ -34,6 +34,7 @@ struct KCParams {
     const float* B; long long ldb;
     float* C; long long ldc;
     const float* bias;
+    const float* bias2; int bias_split;   // columns >= bias_split take bias2[col - bias_split] (two stacked projections)
     const float* res; long long ldres;
     float* aux; long long ldaux;
     int M, N, K;
@@ -54,7 +55,7 @@ __device__ __forceinline__ void kc_epilogue_tile(const KCParams& p, const f32x16
                                                  __amdgpu_buffer_rsrc_t rc, __amdgpu_buffer_rsrc_t rres,
                                                  __amdgpu_buffer_rsrc_t raux) {
     const bool col_ok = col < p.N;
-    const float bv = (p.bias && col_ok) ? p.bias[col] : 0.f;
+    const float bv = (p.bias && col_ok) ? (col < p.bias_split ? p.bias[col] : p.bias2[col - p.bias_split]) : 0.f;
     unsigned offc[16];
     float rv[16], av[16];
 #pragma unroll
@@ -490,6 +491,7 @@ static int conv_chunk(int Cin, int N) { return use_split(N, true, Cin) ? 32 : 16
 static int launch_kc(const KCParams& p_in, bool im2col, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
     KCParams p = p_in;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return PA2D_OK;
+    if (!p.bias2) p.bias_split = 0x7fffffff;
     {   // 32-bit byte offsets inside the buffer descriptors
         const unsigned long long ab = ((unsigned long long)(p.M - 1) * p.lda + (im2col ? p.Cin : p.K)) * 4ull;
         const unsigned long long bb = ((unsigned long long)(p.N - 1) * p.ldb + p.K) * 4ull;
@@ -812,6 +814,8 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
     const float s = ((red[0][tx] + red[1][tx]) + red[2][tx]) + red[3][tx];
     if (mode == 0) {
         out[idx] = s;
+    } else if (mode == 2) {      // one vector split over two outputs at element C
+        if (idx < C) out[idx] = s; else out2[idx - C] = s;
     } else {
         const int ci = (int)(idx % Cin);
         const int tap = (int)((idx / Cin) % 9);
@@ -891,12 +895,14 @@ __global__ void colsum_partial_kernel(const float* __restrict__ X, long long ld,
 
 static int colsum_blocks(int M) { int b = ceil_div(M, 128); return b > 1024 ? 1024 : (b < 1 ? 1 : b); }
 
-static int launch_colsum(const float* X, long long ld, int M, int N, float* out, float* partial, hipStream_t st) {
+// out2 != NULL: columns >= split go to out2[col - split]
+static int launch_colsum(const float* X, long long ld, int M, int N, float* out, float* partial, hipStream_t st,
+                         float* out2 = nullptr, int split = 0) {
     const int nb = colsum_blocks(M);
     const int rpb = ceil_div(M, nb);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, st, X, ld, M, N, rpb, partial);
     PA2D_CHECK_LAUNCH();
-    return launch_reduce(partial, nb, N, out, nullptr, 0, 0, 0, st);
+    return launch_reduce(partial, nb, N, out, out2, out2 ? 2 : 0, split, 0, st);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1047,8 +1053,8 @@ size_t pa2d_conv3x3x2_workspace(int B, int H, int W, int C) {
 // Physics_Attention.py:94,96 — both projections read the same input, so they run as ONE implicit
 // GEMM [B*N, 9C] x [9C, 2C].
 int pa2d_conv3x3x2_fwd(const float* xn, const float* wx, const float* bx, const float* wf, const float* bf,
-                       float* out, float* bias2_ws /* 2C floats */, void* ws, size_t ws_bytes, int B, int H, int W,
-                       int C, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
+                       float* out, void* ws, size_t ws_bytes, int B, int H, int W, int C, hipStream_t st,
+                       hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (ws_bytes < (size_t)3 * C * 9 * C * sizeof(float)) return PA2D_ERR_WORKSPACE;
     float* pack = (float*)ws;
     int rc = PA2D_OK;
@@ -1061,21 +1067,17 @@ int pa2d_conv3x3x2_fwd(const float* xn, const float* wx, const float* bx, const 
         rc = launch_repack(wx, wf, pack, 1, 0, (kc_bk32(true, C) && (long long)ceil_div(B * H * W, 128) * ceil_div(2 * C, 128) >= 384 && 2 * C > 64) ? 32 : 16, C, C, st);
         if (rc) return rc;
     }
-    hipError_t e = hipMemcpyAsync(bias2_ws, bx, C * sizeof(float), hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemcpyAsync(bias2_ws + C, bf, C * sizeof(float), hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) return (int)e;
     KCParams p = {};
-    p.A = xn; p.lda = C; p.B = pack; p.ldb = 9 * C; p.C = out; p.ldc = 2 * C; p.bias = bias2_ws;
+    p.A = xn; p.lda = C; p.B = pack; p.ldb = 9 * C; p.C = out; p.ldc = 2 * C;
+    p.bias = bx; p.bias2 = bf; p.bias_split = C;
     p.M = B * H * W; p.N = 2 * C; p.K = 9 * C; p.H = H; p.W = W; p.Cin = C;
     return launch_kc(p, true, st, ev_start, ev_stop);
 }
 
 // dxn[B*N, C] (+= nothing; plain store), dwx/dwf [C,C,3,3], dbx/dbf [C]  from dout[B*N, 2C]
 int pa2d_conv3x3x2_bwd(const float* dout, const float* xn, const float* wx, const float* wf, float* dxn, float* dwx,
-                       float* dbx, float* dwf, float* dbf, float* dbias2_ws /* 2C floats */, void* ws,
-                       size_t ws_bytes, int B, int H, int W, int C, hipStream_t st, hipEvent_t ev_start,
-                       hipEvent_t ev_stop) {
+                       float* dbx, float* dwf, float* dbf, void* ws, size_t ws_bytes, int B, int H, int W, int C,
+                       hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (ws_bytes < pa2d_conv3x3x2_workspace(B, H, W, C)) return PA2D_ERR_WORKSPACE;
     float* pack = (float*)ws;
     float* scratch = pack + (size_t)3 * C * 9 * C;
@@ -1101,13 +1103,7 @@ int pa2d_conv3x3x2_bwd(const float* dout, const float* xn, const float* wx, cons
     if (rc) return rc;
     rc = launch_reduce(scratch, pl.splits, (long long)2 * C * 9 * C, dwx, dwf, 1, C, C, st);
     if (rc) return rc;
-    rc = launch_colsum(dout, 2 * C, M, 2 * C, dbias2_ws, scratch, st);
-    if (rc) return rc;
-    hipError_t e = hipMemcpyAsync(dbx, dbias2_ws, C * sizeof(float), hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemcpyAsync(dbf, dbias2_ws + C, C * sizeof(float), hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) return (int)e;
-    return PA2D_OK;
+    return launch_colsum(dout, 2 * C, M, 2 * C, dbx, scratch, st, dbf, C);
 }
 
 }  // extern "C"

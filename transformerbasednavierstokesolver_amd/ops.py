@@ -119,11 +119,10 @@ def conv3x3x2_fwd(xn, wx, bx, wf, bf, H, W):
     _chk(xn, wx, bx, wf, bf)
     B, N, Cc = xn.shape
     out = torch.empty(B, N, 2 * Cc, dtype=torch.float32, device=xn.device)
-    bias2 = torch.empty(2 * Cc, dtype=torch.float32, device=xn.device)
     nb = _L().pa2d_conv3x3x2_workspace(B, H, W, Cc)
     ws = _ws(nb, xn)
     e0, e1 = _conv_events()
-    _lib.check(_L().pa2d_conv3x3x2_fwd(_p(xn), _p(wx), _p(bx), _p(wf), _p(bf), _p(out), _p(bias2), ws.data_ptr(), nb,
+    _lib.check(_L().pa2d_conv3x3x2_fwd(_p(xn), _p(wx), _p(bx), _p(wf), _p(bf), _p(out), ws.data_ptr(), nb,
                                        B, H, W, Cc, _stream(), e0, e1), "conv3x3x2_fwd")
     return out
 
@@ -135,12 +134,11 @@ def conv3x3x2_bwd(dout, xn, wx, wf, H, W, need_dx=True):
     dwx, dwf = torch.empty_like(wx), torch.empty_like(wf)
     dbx = torch.empty(Cc, dtype=torch.float32, device=xn.device)
     dbf = torch.empty_like(dbx)
-    db2 = torch.empty(2 * Cc, dtype=torch.float32, device=xn.device)
     nb = _L().pa2d_conv3x3x2_workspace(B, H, W, Cc)
     ws = _ws(nb, xn)
     e0, e1 = _conv_events() if need_dx else (0, 0)
     _lib.check(_L().pa2d_conv3x3x2_bwd(_p(dout), _p(xn), _p(wx), _p(wf), _p(dxn), _p(dwx), _p(dbx), _p(dwf), _p(dbf),
-                                       _p(db2), ws.data_ptr(), nb, B, H, W, Cc, _stream(), e0, e1), "conv3x3x2_bwd")
+                                       ws.data_ptr(), nb, B, H, W, Cc, _stream(), e0, e1), "conv3x3x2_bwd")
     return dxn, dwx, dbx, dwf, dbf
 
 
@@ -176,7 +174,7 @@ def token_attn_bwd(s, nrm, wq, wk, wv, dopart):
     BH, nchunk, M, D = dopart.shape
     ds = torch.empty_like(s)
     dn = torch.empty_like(nrm)
-    dwq, dwk, dwv = torch.empty_like(wq), torch.empty_like(wk), torch.empty_like(wv)
+    dwq, dwk, dwv = torch.empty(3, D, D, dtype=torch.float32, device=s.device).unbind(0)   # one block: reduced in place
     nb = _L().pa2d_token_attn_bwd_workspace(BH, D)
     ws = _ws(nb, s)
     _lib.check(_L().pa2d_token_attn_bwd(_p(s), _p(nrm), _p(wq), _p(wk), _p(wv), _p(dopart), _p(ds), _p(dn), _p(dwq),
