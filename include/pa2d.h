@@ -78,13 +78,22 @@ int pa2d_gemm_bwd_weight(const float* dy, long long lddy, const float* x, long l
  * implicit-GEMM launch (forward: the [B*N,9C]x[9C,2C] product; backward: the data-gradient product),
  * so a benchmark can time that kernel alone without a profiler. */
 size_t pa2d_conv3x3x2_workspace(int B, int H, int W, int C);
+/* Packed weights.  The implicit GEMM reads the two [C,C,3,3] kernels from a K-major pack whose layout depends on
+ * the tile / K-step chosen for (B,H,W,C) and on the GEMM mode.  By default fwd/bwd build it per call into `ws`
+ * (weights change every optimizer step).  A caller that knows the weights are constant over several calls (the
+ * T/step calls of one training iteration, a rollout) packs once with pa2d_conv3x3x2_pack and passes the result
+ * as `prepacked`; direction 0 = forward pack, 1 = data-gradient pack (taps flipped, in/out swapped). */
+size_t pa2d_conv3x3x2_pack_bytes(int C);
+int pa2d_conv3x3x2_pack(const float* wx, const float* wf, void* pack, size_t pack_bytes, int B, int H, int W,
+                        int C, int direction, pa2d_stream_t stream);
 int pa2d_conv3x3x2_fwd(const float* xn, const float* wx, const float* bx, const float* wf, const float* bf,
-                       float* out, void* ws, size_t ws_bytes, int B, int H, int W, int C,
-                       pa2d_stream_t stream, void* ev_start, void* ev_stop);
+                       float* out, const void* prepacked /* NULL = pack here */, void* ws, size_t ws_bytes,
+                       int B, int H, int W, int C, pa2d_stream_t stream, void* ev_start, void* ev_stop);
 /* dxn may be NULL (input needs no gradient) */
 int pa2d_conv3x3x2_bwd(const float* dout, const float* xn, const float* wx, const float* wf, float* dxn,
-                       float* dwx, float* dbx, float* dwf, float* dbf, void* ws, size_t ws_bytes, int B, int H,
-                       int W, int C, pa2d_stream_t stream, void* ev_start, void* ev_stop);
+                       float* dwx, float* dbx, float* dwf, float* dbf, const void* prepacked /* NULL = pack here */,
+                       void* ws, size_t ws_bytes, int B, int H, int W, int C, pa2d_stream_t stream,
+                       void* ev_start, void* ev_stop);
 
 /* ---- slice: softmax((x_mid . Ws^T + bs) / clamp(temperature, .1, 5)) and the weighted scatter of
  * N points into M tokens, Physics_Attention.py:98-101.  Emits per-chunk partial sums

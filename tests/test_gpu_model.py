@@ -320,3 +320,37 @@ def test_full_bench_batch_consistency_and_determinism():
         acc = gs if acc is None else {k: acc[k] + gs[k] for k in acc}
     for k in g1:
         assert rel_l2(acc[k], g1[k]) < (2e-3 if ("to_q" in k or "to_k" in k) else 1e-4), k
+
+
+def test_frozen_weight_packs_follow_weight_updates():
+    """ops.weights_frozen(): (a) a scoped rollout (conv weights packed once per layer) is bit-identical to
+    unscoped model calls (packed per call); (b) a GraphedRollout whose captured step only references the packs
+    still sees parameters changed after the capture, even through `.data` (which bumps no version counter):
+    run() refreshes the packs in place."""
+    from transformerbasednavierstokesolver_amd import synth, harness, ops
+    cfg = dict(synth.NS_SMALL_CONFIG, n_layers=2)
+    m = harness.build_model(cfg, synth.synth_state_dict(cfg, seed=61), DEV).eval()
+    pos, a, _ = synth.ns_batch(2, seed=62)
+    x, fx = torch.from_numpy(pos).to(DEV), torch.from_numpy(a).to(DEV)
+
+    def unscoped(n):
+        frames, w = [], fx
+        with torch.no_grad():
+            for _ in range(n):
+                assert not ops._frozen
+                im = m(x, fx=w)
+                frames.append(im)
+                w = torch.cat((w[..., 1:], im), dim=-1)
+        return torch.cat(frames, -1)
+
+    assert torch.equal(harness.rollout(m, x, fx, 4), unscoped(4))
+    gr = harness.GraphedRollout(m, x, fx)
+    assert len(gr.packs.packs) == cfg["n_layers"]
+    assert torch.equal(gr.run(fx, 4), unscoped(4))
+    with torch.no_grad():
+        for blk in m.blocks:
+            blk.Attn.in_project_x.weight.data.mul_(1.25)
+            blk.Attn.in_project_fx.weight.data.add_(0.01)
+    after = unscoped(4)
+    assert not torch.equal(after[..., 0], gr.im[..., 0])
+    assert torch.equal(gr.run(fx, 4), after)

@@ -25,6 +25,7 @@
 #include "pa2d_internal.h"
 #include <stdlib.h>
 
+#define KC_BK_SMALL_DEFAULT 1
 #define EPI_ACT 1        // out = act(acc + bias)
 #define EPI_STORE_PRE 2  // aux = acc + bias   (pre-activation, saved for backward)
 #define EPI_MUL_DACT 4   // out = acc * act'(aux)
@@ -480,6 +481,25 @@ static bool kc_bk32(bool im2col, int Cin) {
     if (v < 0) { const char* e = getenv("PA2D_KC_BK"); v = (e && atoi(e) == 16) ? 0 : 1; }
     return v && (!im2col || (Cin % 32) == 0);
 }
+// K-step of the small tiles (128x64, 64x64: batch-1 rollout and small-batch training); PA2D_KC_BK_SMALL=16|32
+static bool kc_bk32_small(bool im2col, int Cin) {
+    static int v = -1;
+    if (v < 0) { const char* e = getenv("PA2D_KC_BK_SMALL"); v = e ? (atoi(e) == 32) : KC_BK_SMALL_DEFAULT; }
+    return v && (!im2col || (Cin % 32) == 0);
+}
+// tile choice of the fp32 engine: 128x128 when that already gives >= 1.5 workgroups per CU, otherwise smaller
+// tiles so that small problems (rollout at batch 1: M = 4096) still fill the 256 CUs.  Shared by the launch and
+// by the conv weight packs (the pack's channel chunk must equal the K-step).
+struct KCTile { int bm, bn, bk; };
+static KCTile kc_tile(int M, int N, bool im2col, int Cin) {
+    const int tiles_m = ceil_div(M, 128);
+    const long long t128 = (long long)tiles_m * ceil_div(N, 128);
+    const long long t12864 = (long long)tiles_m * ceil_div(N, 64);
+    if (N > 64 && t128 >= 384) return {128, 128, kc_bk32(im2col, Cin) ? 32 : 16};
+    const int bk = kc_bk32_small(im2col, Cin) ? 32 : 16;
+    if (t12864 >= 384 || M <= 64) return {128, 64, bk};
+    return {64, 64, bk};
+}
 static bool use_split(int N, bool im2col, int Cin) {
     const int m = gemm_mode();
     if (m == 1) return im2col && N > 64 && (Cin % 32) == 0;
@@ -532,29 +552,23 @@ static int launch_kc(const KCParams& p_in, bool im2col, hipStream_t st, hipEvent
             else hipLaunchKernelGGL((gemm_kc_split_kernel<128, 128, false, 3>), grid, dim3(512), smem, st, p);
         }
     } else {
-        // tile choice: 128x128 when that already gives >= 1.5 workgroups per CU, otherwise smaller tiles
-        // so that small problems (rollout at batch 1: M = 4096) still fill the 256 CUs
-        const long long t128 = (long long)tiles_m * ceil_div(p.N, 128);
-        const long long t12864 = (long long)tiles_m * ceil_div(p.N, 64);
-        if (p.N > 64 && t128 >= 384) {
-            const int tiles_n = ceil_div(p.N, 128);
-            const dim3 grid(ceil_div(tiles_m, 8) * 8 * tiles_n);
-            if (kc_bk32(im2col, p.Cin)) {
-                if (im2col) hipLaunchKernelGGL((gemm_kc_kernel<128, 128, 2, 2, true, 32>), grid, dim3(256), 0, st, p);
-                else hipLaunchKernelGGL((gemm_kc_kernel<128, 128, 2, 2, false, 32>), grid, dim3(256), 0, st, p);
-            } else if (im2col) hipLaunchKernelGGL((gemm_kc_kernel<128, 128, 2, 2, true>), grid, dim3(256), 0, st, p);
-            else hipLaunchKernelGGL((gemm_kc_kernel<128, 128, 2, 2, false>), grid, dim3(256), 0, st, p);
-        } else if (t12864 >= 384 || p.M <= 64) {
-            const int tiles_n = ceil_div(p.N, 64);
-            const dim3 grid(ceil_div(tiles_m, 8) * 8 * tiles_n);
-            if (im2col) hipLaunchKernelGGL((gemm_kc_kernel<128, 64, 4, 1, true>), grid, dim3(256), 0, st, p);
-            else hipLaunchKernelGGL((gemm_kc_kernel<128, 64, 4, 1, false>), grid, dim3(256), 0, st, p);
-        } else {
-            const int tm64 = ceil_div(p.M, 64), tiles_n = ceil_div(p.N, 64);
-            const dim3 grid(ceil_div(tm64, 8) * 8 * tiles_n);
-            if (im2col) hipLaunchKernelGGL((gemm_kc_kernel<64, 64, 2, 2, true>), grid, dim3(256), 0, st, p);
-            else hipLaunchKernelGGL((gemm_kc_kernel<64, 64, 2, 2, false>), grid, dim3(256), 0, st, p);
-        }
+        const KCTile t = kc_tile(p.M, p.N, im2col, p.Cin);
+        const int tiles_n = ceil_div(p.N, t.bn);
+        const dim3 grid(ceil_div(ceil_div(p.M, t.bm), 8) * 8 * tiles_n);
+#define KC_GO(BM_, BN_, WM_, WN_)                                                                            \
+    {                                                                                                      \
+        if (t.bk == 32) {                                                                                  \
+            if (im2col) hipLaunchKernelGGL((gemm_kc_kernel<BM_, BN_, WM_, WN_, true, 32>), grid, dim3(256), 0, st, p);  \
+            else hipLaunchKernelGGL((gemm_kc_kernel<BM_, BN_, WM_, WN_, false, 32>), grid, dim3(256), 0, st, p);        \
+        } else {                                                                                           \
+            if (im2col) hipLaunchKernelGGL((gemm_kc_kernel<BM_, BN_, WM_, WN_, true, 16>), grid, dim3(256), 0, st, p);  \
+            else hipLaunchKernelGGL((gemm_kc_kernel<BM_, BN_, WM_, WN_, false, 16>), grid, dim3(256), 0, st, p);        \
+        }                                                                                                  \
+    }
+        if (t.bm == 128 && t.bn == 128) KC_GO(128, 128, 2, 2)
+        else if (t.bm == 128) KC_GO(128, 64, 4, 1)
+        else KC_GO(64, 64, 2, 2)
+#undef KC_GO
     }
     PA2D_CHECK_LAUNCH();
     if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return PA2D_ERR_ARG;
@@ -1049,23 +1063,42 @@ size_t pa2d_conv3x3x2_workspace(int B, int H, int W, int C) {
     return (pack + (sl > cs ? sl : cs)) * sizeof(float);
 }
 
+// Packed conv weights in the layout the engine selected for these dims wants (channel chunk = K-step of the
+// tile, fp32 or bf16 planes by GEMM mode).  direction 0: forward pack ([2C][9C]); 1: data-gradient pack
+// ([C][9*2C], taps flipped).  pack: pa2d_conv3x3x2_pack_bytes(C) bytes.  A pack stays valid while the weights,
+// the dims and the GEMM mode do not change.
+static int conv_pack(const float* wx, const float* wf, float* pack, int M, int C, int direction, hipStream_t st) {
+    const int N = direction ? C : 2 * C, Cin = direction ? 2 * C : C;
+    if (use_split(N, true, Cin)) {
+        hipLaunchKernelGGL(repack_split_kernel, dim3((unsigned)ceil_div_ll((long long)2 * C * 9 * C, 256)), dim3(256), 0, st,
+                           wx, wf, (__bf16*)pack, direction, gemm_mode() == 2 ? 1 : 3, C, C);
+        PA2D_CHECK_LAUNCH();
+        return PA2D_OK;
+    }
+    return launch_repack(wx, wf, pack, direction ? 2 : 1, 0, kc_tile(M, N, true, Cin).bk, C, C, st);
+}
+
+size_t pa2d_conv3x3x2_pack_bytes(int C) { return (size_t)3 * C * 9 * C * sizeof(float); }
+
+int pa2d_conv3x3x2_pack(const float* wx, const float* wf, void* pack, size_t pack_bytes, int B, int H, int W, int C,
+                        int direction, hipStream_t st) {
+    if (pack_bytes < pa2d_conv3x3x2_pack_bytes(C)) return PA2D_ERR_WORKSPACE;
+    return conv_pack(wx, wf, (float*)pack, B * H * W, C, direction ? 1 : 0, st);
+}
+
 // out[B*H*W, 2C] = [conv3x3(xn, wx) + bx | conv3x3(xn, wf) + bf]   (zero padding 1, NHWC)
 // Physics_Attention.py:94,96 — both projections read the same input, so they run as ONE implicit
-// GEMM [B*N, 9C] x [9C, 2C].
+// GEMM [B*N, 9C] x [9C, 2C].  prepacked: NULL (weights are packed into ws by this call) or a pack made by
+// pa2d_conv3x3x2_pack(direction 0) for the same B, H, W, C.
 int pa2d_conv3x3x2_fwd(const float* xn, const float* wx, const float* bx, const float* wf, const float* bf,
-                       float* out, void* ws, size_t ws_bytes, int B, int H, int W, int C, hipStream_t st,
-                       hipEvent_t ev_start, hipEvent_t ev_stop) {
-    if (ws_bytes < (size_t)3 * C * 9 * C * sizeof(float)) return PA2D_ERR_WORKSPACE;
-    float* pack = (float*)ws;
-    int rc = PA2D_OK;
-    const bool presplit_f = use_split(2 * C, true, C);
-    if (presplit_f) {
-        hipLaunchKernelGGL(repack_split_kernel, dim3((unsigned)ceil_div_ll((long long)2 * C * 9 * C, 256)), dim3(256), 0, st,
-                           wx, wf, (__bf16*)pack, 0, gemm_mode() == 2 ? 1 : 3, C, C);
-        PA2D_CHECK_LAUNCH();
-    } else {
-        rc = launch_repack(wx, wf, pack, 1, 0, (kc_bk32(true, C) && (long long)ceil_div(B * H * W, 128) * ceil_div(2 * C, 128) >= 384 && 2 * C > 64) ? 32 : 16, C, C, st);
+                       float* out, const void* prepacked, void* ws, size_t ws_bytes, int B, int H, int W, int C,
+                       hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    const float* pack = (const float*)prepacked;
+    if (!pack) {
+        if (ws_bytes < pa2d_conv3x3x2_pack_bytes(C)) return PA2D_ERR_WORKSPACE;
+        const int rc = conv_pack(wx, wf, (float*)ws, B * H * W, C, 0, st);
         if (rc) return rc;
+        pack = (const float*)ws;
     }
     KCParams p = {};
     p.A = xn; p.lda = C; p.B = pack; p.ldb = 9 * C; p.C = out; p.ldc = 2 * C;
@@ -1076,21 +1109,18 @@ int pa2d_conv3x3x2_fwd(const float* xn, const float* wx, const float* bx, const 
 
 // dxn[B*N, C] (+= nothing; plain store), dwx/dwf [C,C,3,3], dbx/dbf [C]  from dout[B*N, 2C]
 int pa2d_conv3x3x2_bwd(const float* dout, const float* xn, const float* wx, const float* wf, float* dxn, float* dwx,
-                       float* dbx, float* dwf, float* dbf, void* ws, size_t ws_bytes, int B, int H, int W, int C,
-                       hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
+                       float* dbx, float* dwf, float* dbf, const void* prepacked, void* ws, size_t ws_bytes, int B,
+                       int H, int W, int C, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (ws_bytes < pa2d_conv3x3x2_workspace(B, H, W, C)) return PA2D_ERR_WORKSPACE;
-    float* pack = (float*)ws;
-    float* scratch = pack + (size_t)3 * C * 9 * C;
+    float* scratch = (float*)ws + (size_t)3 * C * 9 * C;
     const int M = B * H * W;
     int rc;
     if (dxn) {
-        if (use_split(C, true, 2 * C)) {
-            hipLaunchKernelGGL(repack_split_kernel, dim3((unsigned)ceil_div_ll((long long)2 * C * 9 * C, 256)), dim3(256), 0,
-                               st, wx, wf, (__bf16*)pack, 1, gemm_mode() == 2 ? 1 : 3, C, C);
-            PA2D_CHECK_LAUNCH();
-        } else {
-            rc = launch_repack(wx, wf, pack, 2, 0, (kc_bk32(true, 2 * C) && (long long)ceil_div(M, 128) * ceil_div(C, 128) >= 384 && C > 64) ? 32 : 16, C, C, st);
+        const float* pack = (const float*)prepacked;
+        if (!pack) {
+            rc = conv_pack(wx, wf, (float*)ws, M, C, 1, st);
             if (rc) return rc;
+            pack = (const float*)ws;
         }
         KCParams p = {};
         p.A = dout; p.lda = 2 * C; p.B = pack; p.ldb = 9 * 2 * C; p.C = dxn; p.ldc = C;

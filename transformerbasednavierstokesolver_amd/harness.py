@@ -18,6 +18,7 @@ from __future__ import annotations
 
 import torch
 
+from . import ops
 from .model.Transolver_Structured_Mesh_2D import Model
 from .utils.testloss import TestLoss
 
@@ -84,9 +85,10 @@ def train_step(model, optimizer, scheduler, x, fx, yy, step=1, max_grad_norm=Non
     the optimizer step (all-reduce SUM of the flat gradient bucket).  With `optim.FusedAdamW` pass
     `grad_sync=optimizer.sync` (same bucket) and put the clip threshold in the optimizer instead of
     `max_grad_norm`."""
-    loss, full, _ = train_iteration(model, x, fx, yy, step, loss_fn, fold_time)
-    optimizer.zero_grad(set_to_none=set_to_none)
-    loss.backward()
+    with ops.weights_frozen():       # no parameter moves between the first model call and the end of backward
+        loss, full, _ = train_iteration(model, x, fx, yy, step, loss_fn, fold_time)
+        optimizer.zero_grad(set_to_none=set_to_none)
+        loss.backward()
     if grad_sync is not None:
         grad_sync()
     if max_grad_norm is not None:
@@ -100,10 +102,11 @@ def train_step(model, optimizer, scheduler, x, fx, yy, step=1, max_grad_norm=Non
 @torch.no_grad()
 def rollout(model, x, fx, nsteps, step=1):
     frames = []
-    for _ in range(nsteps):
-        im = model(x, fx=fx)
-        frames.append(im)
-        fx = torch.cat((fx[..., step:], im), dim=-1)
+    with ops.weights_frozen():
+        for _ in range(nsteps):
+            im = model(x, fx=fx)
+            frames.append(im)
+            fx = torch.cat((fx[..., step:], im), dim=-1)
     return torch.cat(frames, -1)
 
 
@@ -121,13 +124,16 @@ class GraphedRollout:
         self.graph = torch.cuda.CUDAGraph()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), torch.no_grad():
-            for _ in range(warmup):
+        # the conv weight packs are made during the warm-up and only REFERENCED by the captured step; run()
+        # refreshes them in place before replaying, so later weight updates (training between rollouts) are seen
+        with ops.weights_frozen() as self.packs:
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(warmup):
+                    self._step_eager()
+            torch.cuda.current_stream().wait_stream(side)
+            self.fx.copy_(fx)
+            with torch.no_grad(), torch.cuda.graph(self.graph):
                 self._step_eager()
-        torch.cuda.current_stream().wait_stream(side)
-        self.fx.copy_(fx)
-        with torch.no_grad(), torch.cuda.graph(self.graph):
-            self._step_eager()
         self.fx.copy_(fx)
 
     def _step_eager(self):
@@ -140,6 +146,7 @@ class GraphedRollout:
     @torch.no_grad()
     def run(self, fx0, nsteps):
         self.fx.copy_(fx0)
+        self.packs.refresh()
         frames = []
         for _ in range(nsteps):
             self.graph.replay()
@@ -182,10 +189,11 @@ class GraphedTrainStep:
             self.loss, self.full = self._fwd_bwd()
 
     def _fwd_bwd(self):
-        self.opt.zero_grad()
-        loss, full, _ = train_iteration(self.model, self.x, self.fx, self.yy, self.step_size, self.loss_fn,
-                                        self.fold_time)
-        loss.backward()
+        with ops.weights_frozen():      # inside the capture: each layer's weights are packed once per replay
+            self.opt.zero_grad()
+            loss, full, _ = train_iteration(self.model, self.x, self.fx, self.yy, self.step_size, self.loss_fn,
+                                            self.fold_time)
+            loss.backward()
         return loss.detach(), full
 
     def __call__(self, x, fx, yy):

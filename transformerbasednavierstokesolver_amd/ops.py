@@ -114,15 +114,65 @@ def linear_bwd_weight(dy, x2d, want_bias=True):
     return dw, db
 
 
+# ---------------------------------------------------------------------------------------------- conv weight packs
+class _FrozenScope:
+    """Book-keeping of one `weights_frozen()` scope: packs made inside it, keyed by (weights, dims, direction)."""
+
+    def __init__(self):
+        self.packs = {}
+
+    def refresh(self):
+        """Re-pack every entry in place (same device pointers): called before replaying a hipGraph that was captured
+        inside this scope, so the graph's conv launches always see the current weights."""
+        for (_, _, B, H, W, Cc, direction), (wx, wf, pack) in self.packs.items():
+            _lib.check(_L().pa2d_conv3x3x2_pack(_p(wx), _p(wf), pack.data_ptr(), pack.numel(), B, H, W, Cc, direction,
+                                                _stream()), "conv3x3x2_pack")
+
+
+_frozen = []      # stack of active scopes
+
+
+class weights_frozen:
+    """Context manager declaring that no parameter changes inside it (the model calls + backward of one training
+    iteration, a rollout).  Inside, the K-major pack of each layer's conv weights is built on first use and
+    reused by later calls; outside a scope every conv call packs its weights itself (always correct, whatever
+    changed the weights).  `with weights_frozen() as scope:` exposes `scope.refresh()`."""
+
+    def __enter__(self):
+        _frozen.append(_FrozenScope())
+        return _frozen[-1]
+
+    def __exit__(self, *exc):
+        _frozen.pop()
+        return False
+
+
+def _conv_pack(wx, wf, B, H, W, Cc, direction):
+    """Pack pointer for the active scope (0 = let the conv call pack into its workspace)."""
+    if not _frozen:
+        return 0
+    scope = _frozen[-1]
+    key = (wx.data_ptr(), wf.data_ptr(), B, H, W, Cc, direction)
+    hit = scope.packs.get(key)
+    if hit is None:
+        nb = _L().pa2d_conv3x3x2_pack_bytes(Cc)
+        pack = torch.empty(nb, dtype=torch.uint8, device=wx.device)
+        _lib.check(_L().pa2d_conv3x3x2_pack(_p(wx), _p(wf), pack.data_ptr(), nb, B, H, W, Cc, direction, _stream()),
+                   "conv3x3x2_pack")
+        hit = scope.packs[key] = (wx, wf, pack)
+    return hit[2].data_ptr()
+
+
 def conv3x3x2_fwd(xn, wx, bx, wf, bf, H, W):
     """xn [B,N,C] -> [B,N,2C] = [x_mid | fx_mid]."""
     _chk(xn, wx, bx, wf, bf)
     B, N, Cc = xn.shape
     out = torch.empty(B, N, 2 * Cc, dtype=torch.float32, device=xn.device)
-    nb = _L().pa2d_conv3x3x2_workspace(B, H, W, Cc)
+    pre = _conv_pack(wx, wf, B, H, W, Cc, 0)
+    nb = 0 if pre else _L().pa2d_conv3x3x2_pack_bytes(Cc)
     ws = _ws(nb, xn)
     e0, e1 = _conv_events()
-    _lib.check(_L().pa2d_conv3x3x2_fwd(_p(xn), _p(wx), _p(bx), _p(wf), _p(bf), _p(out), ws.data_ptr(), nb,
+    _lib.check(_L().pa2d_conv3x3x2_fwd(_p(xn), _p(wx), _p(bx), _p(wf), _p(bf), _p(out), pre, ws.data_ptr(), nb,
                                        B, H, W, Cc, _stream(), e0, e1), "conv3x3x2_fwd")
     return out
 
@@ -136,9 +186,10 @@ def conv3x3x2_bwd(dout, xn, wx, wf, H, W, need_dx=True):
     dbf = torch.empty_like(dbx)
     nb = _L().pa2d_conv3x3x2_workspace(B, H, W, Cc)
     ws = _ws(nb, xn)
+    pre = _conv_pack(wx, wf, B, H, W, Cc, 1) if need_dx else 0
     e0, e1 = _conv_events() if need_dx else (0, 0)
     _lib.check(_L().pa2d_conv3x3x2_bwd(_p(dout), _p(xn), _p(wx), _p(wf), _p(dxn), _p(dwx), _p(dbx), _p(dwf), _p(dbf),
-                                       ws.data_ptr(), nb, B, H, W, Cc, _stream(), e0, e1), "conv3x3x2_bwd")
+                                       pre, ws.data_ptr(), nb, B, H, W, Cc, _stream(), e0, e1), "conv3x3x2_bwd")
     return dxn, dwx, dbx, dwf, dbf
 
 
