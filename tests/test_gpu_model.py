@@ -354,3 +354,58 @@ def test_frozen_weight_packs_follow_weight_updates():
     after = unscoped(4)
     assert not torch.equal(after[..., 0], gr.im[..., 0])
     assert torch.equal(gr.run(fx, 4), after)
+
+
+def test_empty_batch_forward_and_backward():
+    """B = 0 (the reference's PyTorch ops accept it): the output is [0,N,out_dim], backward runs and every
+    parameter on the path gets an exactly-zero gradient — reductions over an empty set are zero-filled by
+    libpa2d, maps are no-ops, no kernel is launched with an empty grid."""
+    from transformerbasednavierstokesolver_amd import synth, harness
+    cfg = dict(synth.NS_SMALL_CONFIG, n_layers=2)
+    m = harness.build_model(cfg, synth.synth_state_dict(cfg, seed=71), DEV).train()
+    pos, a, _ = synth.ns_batch(1, seed=72)
+    x, fx = torch.from_numpy(pos).to(DEV), torch.from_numpy(a).to(DEV)
+    out = m(x[:0], fx=fx[:0])
+    assert out.shape == (0, cfg["H"] * cfg["W"], cfg["out_dim"])
+    out.sum().backward()
+    seen = 0
+    for k, p in m.named_parameters():
+        if k == "placeholder":
+            continue
+        assert p.grad is not None and p.grad.shape == p.shape and not p.grad.any(), k
+        seen += 1
+    assert seen == len(synth.state_dict_spec(cfg)) - 1
+    with torch.no_grad():
+        assert m(x[:0], fx=fx[:0]).shape[0] == 0
+
+
+def test_c_abi_error_codes_on_device():
+    """Error behaviour of the boundary: contract violations come back as PA2D_ERR_* codes (and RuntimeError in the
+    ctypes layer) BEFORE anything is launched."""
+    from transformerbasednavierstokesolver_amd import _lib, ops
+    L = _lib.load()
+    t = torch.zeros(64 * 64, device=DEV)
+    ptr = t.data_ptr()
+    st = torch.cuda.current_stream().cuda_stream
+    # K not a multiple of 4 -> ARG
+    assert L.pa2d_gemm_bias_act_fwd(ptr, 6, ptr, 6, 0, 0, 8, ptr, 8, 0, 8, 16, 8, 6, 0, st) == 1001
+    # LayerNorm width not a multiple of 4 -> UNSUPPORTED
+    assert L.pa2d_layernorm_fwd(ptr, ptr, ptr, ptr, ptr, ptr, 4, 30, 1e-5, st) == 1002
+    # more slices than the token kernel holds -> UNSUPPORTED
+    assert L.pa2d_token_attn_fwd(ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, 1, 1, 129, 8, st) == 1002
+    # head dim outside {8,16,32,64} -> ARG/UNSUPPORTED
+    assert L.pa2d_slice_scatter(ptr, 12, ptr, 12, ptr, ptr, ptr, ptr, ptr, 1, 16, 1, 12, 8, 1, st) in (1001, 1002)
+    # workspace too small -> WORKSPACE
+    assert L.pa2d_gemm_bwd_weight(ptr, 8, ptr, 8, ptr, ptr, ptr, 16, 64, 8, 8, st) == 1003
+    assert L.pa2d_conv3x3x2_fwd(ptr, ptr, ptr, ptr, ptr, ptr, 0, ptr, 16, 1, 4, 4, 16, st, 0, 0) == 1003
+    # a problem whose operand would exceed the 4 GiB buffer-descriptor extent -> UNSUPPORTED (nothing launched)
+    assert L.pa2d_gemm_bias_act_fwd(ptr, 512, ptr, 512, 0, 0, 512, ptr, 512, 0, 512, 2200000, 512, 512, 0, st) == 1002
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="PA2D_ERR"):
+        _lib.check(1002, "probe")
+    with pytest.raises(TypeError):
+        ops.linear_fwd(t.view(64, 64).double(), t.view(64, 64))
+    with pytest.raises(ValueError):
+        ops.linear_fwd(t.view(64, 64).t(), t.view(64, 64))
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.linear_fwd(torch.zeros(4, 4), torch.zeros(4, 4))

@@ -192,3 +192,30 @@ def test_time_folded_iteration_matches_sequential_calls():
         params.append(dict(m.named_parameters()))
     for k in params[0]:
         assert rel_l2(params[1][k], params[0][k]) < 2e-5, k
+
+
+def test_time_folding_splits_into_groups_under_the_descriptor_limit(monkeypatch):
+    """fold_time must never build a call whose widest activation exceeds the 4 GiB buffer-descriptor extent: with
+    the limit lowered so that only 4 of the 10 calls fit, the iteration runs as 3 groups (4+4+2) and still matches
+    the sequential loop."""
+    from transformerbasednavierstokesolver_amd import synth, harness
+    from transformerbasednavierstokesolver_amd.utils.testloss import FusedTestLoss
+    cfg = dict(synth.NS_SMALL_CONFIG, n_layers=2)
+    sd = synth.synth_state_dict(cfg, seed=181)
+    pos, a, u = synth.ns_batch(2, seed=182)
+    x, fx, yy = (torch.from_numpy(t).to(DEV) for t in (pos, a, u))
+    m = harness.build_model(cfg, sd, DEV).train()
+    assert harness._fold_group(m, 2, 4096, 10) == 10
+    assert harness._fold_group(harness.build_model(synth.NS_CONFIG, None, "cpu"), 64, 4096, 10) == 7   # B=64, C=256
+    monkeypatch.setattr(harness, "FOLD_MAX_BYTES", 4 * 2 * 64 * (4 * 2 * 4096) + 100)
+    assert harness._fold_group(m, 2, 4096, 10) == 4
+    calls = []
+    orig = m.forward
+    m.forward = lambda *a_, **k_: (calls.append(a_[0].shape[0]), orig(*a_, **k_))[1]
+    lf = FusedTestLoss(size_average=False)
+    loss_f, full_f, pred_f = harness.train_iteration(m, x, fx, yy, loss_fn=lf, fold_time=True)
+    assert calls == [8, 8, 4]
+    m.forward = orig
+    loss_s, full_s, pred_s = harness.train_iteration(m, x, fx, yy, loss_fn=lf)
+    assert rel_l2(pred_f.detach(), pred_s.detach()) < 2e-6
+    assert abs(float(loss_f.detach()) - float(loss_s.detach())) < 2e-6 * abs(float(loss_s.detach()))

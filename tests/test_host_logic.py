@@ -159,3 +159,16 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/libpa2d.so")
     with pytest.raises(_lib.NativeLibraryMissing):
         _lib.load()
+
+
+def test_size_helpers_accept_empty_problems():
+    """Host-side planners of the C ABI must not divide by zero for batch 0 / N 0 (the entry points then zero-fill
+    reductions and skip the launches)."""
+    from transformerbasednavierstokesolver_amd import _lib
+    lib = _lib.load()
+    assert lib.pa2d_gemm_bwd_weight_workspace(0, 64, 64) > 0
+    assert lib.pa2d_conv3x3x2_workspace(0, 64, 64, 64) >= lib.pa2d_conv3x3x2_pack_bytes(64)
+    assert lib.pa2d_layernorm_bwd_workspace(0, 64) >= 0 and lib.pa2d_head_bwd_workspace(0, 64, 1) >= 0
+    assert lib.pa2d_slice_bwd_workspace(0, 4096, 8, 8, 32) >= 0 and lib.pa2d_sumsq_workspace(0) >= 0
+    assert lib.pa2d_slice_nchunk(0, 4096, 8) >= 1 and lib.pa2d_slice_nchunk(1, 0, 8) == 1
+    assert lib.pa2d_token_attn_bwd_workspace(0, 8) >= 0

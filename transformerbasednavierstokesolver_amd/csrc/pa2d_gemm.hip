@@ -768,6 +768,7 @@ struct MCPlan { int big; int splits; int chunks_per_split; size_t slab_floats; }
 
 static MCPlan plan_mc(int Mi, int Nj, int Mk) {
     MCPlan pl;
+    if (Mk < 1) Mk = 1;       // empty contraction (batch 0): plan as one chunk, the entry points zero-fill instead
     pl.big = (Mi > 64 && Nj > 64) ? 1 : 0;
     const int bm = pl.big ? 128 : 64;
     const int tiles = ceil_div(Mi, bm) * ceil_div(Nj, bm);
@@ -1028,6 +1029,7 @@ int pa2d_gemm_bwd_data(const float* dy, long long lddy, const float* w, long lon
                        hipStream_t st) {
     if (ldw != K) return PA2D_ERR_ARG;
     if (N & 3) return PA2D_ERR_ARG;
+    if (M <= 0) return PA2D_OK;
     int rc = launch_repack(w, nullptr, wt_ws, 0, N, K, 0, 0, st);
     if (rc) return rc;
     KCParams p = {};
@@ -1046,6 +1048,7 @@ size_t pa2d_gemm_bwd_weight_workspace(int M, int N, int K) {
 // dw[N,K] = dy[M,N]^T . x[M,K] ; db[N] = column sums of dy (db may be NULL)
 int pa2d_gemm_bwd_weight(const float* dy, long long lddy, const float* x, long long ldx, float* dw, float* db,
                          void* ws, size_t ws_bytes, int M, int N, int K, hipStream_t st) {
+    if (M <= 0) { const int rz = pa2d_zero(dw, sizeof(float) * N * K, st); return rz ? rz : pa2d_zero(db, sizeof(float) * N, st); }
     if (ws_bytes < pa2d_gemm_bwd_weight_workspace(M, N, K)) return PA2D_ERR_WORKSPACE;
     const MCPlan pl = plan_mc(N, K, M);
     int rc = launch_mc(dy, lddy, N, x, ldx, K, M, false, 0, 0, 0, (float*)ws, pl, st);
@@ -1093,6 +1096,7 @@ int pa2d_conv3x3x2_pack(const float* wx, const float* wf, void* pack, size_t pac
 int pa2d_conv3x3x2_fwd(const float* xn, const float* wx, const float* bx, const float* wf, const float* bf,
                        float* out, const void* prepacked, void* ws, size_t ws_bytes, int B, int H, int W, int C,
                        hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    if (B <= 0) return PA2D_OK;
     const float* pack = (const float*)prepacked;
     if (!pack) {
         if (ws_bytes < pa2d_conv3x3x2_pack_bytes(C)) return PA2D_ERR_WORKSPACE;
@@ -1111,6 +1115,13 @@ int pa2d_conv3x3x2_fwd(const float* xn, const float* wx, const float* bx, const 
 int pa2d_conv3x3x2_bwd(const float* dout, const float* xn, const float* wx, const float* wf, float* dxn, float* dwx,
                        float* dbx, float* dwf, float* dbf, const void* prepacked, void* ws, size_t ws_bytes, int B,
                        int H, int W, int C, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    if (B <= 0) {
+        const size_t wb = sizeof(float) * (size_t)C * C * 9, bb = sizeof(float) * C;
+        int rz = pa2d_zero(dwx, wb, st);
+        if (!rz) rz = pa2d_zero(dwf, wb, st);
+        if (!rz) rz = pa2d_zero(dbx, bb, st);
+        return rz ? rz : pa2d_zero(dbf, bb, st);
+    }
     if (ws_bytes < pa2d_conv3x3x2_workspace(B, H, W, C)) return PA2D_ERR_WORKSPACE;
     float* scratch = (float*)ws + (size_t)3 * C * 9 * C;
     const int M = B * H * W;

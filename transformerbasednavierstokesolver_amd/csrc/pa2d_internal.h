@@ -115,5 +115,10 @@ __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned vo
     __builtin_amdgcn_raw_buffer_store_b128(u, r, voff, 0, 0);
 }
 
+// empty problems (batch 0): maps are no-ops, reductions produce exact zeros
+static inline int pa2d_zero(void* p, size_t bytes, hipStream_t st) {
+    if (!p || !bytes) return PA2D_OK;
+    return (int)hipMemsetAsync(p, 0, bytes, st);
+}
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline long long ceil_div_ll(long long a, long long b) { return (a + b - 1) / b; }

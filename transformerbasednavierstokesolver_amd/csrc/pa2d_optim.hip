@@ -124,6 +124,7 @@ size_t pa2d_sumsq_workspace(long long n) { return sizeof(float) * (size_t)stream
 
 // out[0] = sum_i g[i]^2
 int pa2d_sumsq(const float* g, long long n, float* out, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (n <= 0) return pa2d_zero(out, sizeof(float), st);
     if (ws_bytes < pa2d_sumsq_workspace(n) || (((uintptr_t)g) & 15)) return PA2D_ERR_ARG;
     const int nb = stream_blocks(n);
     hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nb), dim3(256), 0, st, g, n, (float*)ws);
@@ -136,6 +137,7 @@ int pa2d_adamw_step(float* p, const float* g, float* m, float* v, long long n, f
                     float eps, float weight_decay, int step_index, const float* gnorm_sq, float max_norm,
                     hipStream_t st) {
     if (step_index < 1 || ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15)) return PA2D_ERR_ARG;
+    if (n <= 0) return PA2D_OK;
     AdamParams a;
     a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
     a.wd = weight_decay; a.max_norm = max_norm; a.gnorm_sq = gnorm_sq;
@@ -149,6 +151,7 @@ int pa2d_adamw_step(float* p, const float* g, float* m, float* v, long long n, f
 // dnorm, ynorm, ratio: [B]; the caller sums `ratio` (B values) for the batch-summed loss
 int pa2d_rel_l2_fwd(const float* pred, const float* y, float* dnorm, float* ynorm, float* ratio, int B, long long L,
                     hipStream_t st) {
+    if (B <= 0) return PA2D_OK;
     hipLaunchKernelGGL(rel_l2_fwd_kernel, dim3(B), dim3(256), 0, st, pred, y, L, dnorm, ynorm, ratio);
     PA2D_CHECK_LAUNCH();
     return PA2D_OK;
@@ -156,6 +159,7 @@ int pa2d_rel_l2_fwd(const float* pred, const float* y, float* dnorm, float* ynor
 
 int pa2d_rel_l2_bwd(const float* pred, const float* y, const float* dnorm, const float* ynorm, const float* gout,
                     float* dpred, int B, long long L, hipStream_t st) {
+    if (B <= 0 || L <= 0) return PA2D_OK;
     int bx = (int)ceil_div_ll(L, 1024);
     if (bx > 256) bx = 256;
     if (bx < 1) bx = 1;

@@ -226,6 +226,7 @@ extern "C" {
 int pa2d_layernorm_fwd(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd, int rows,
                        int C, float eps, hipStream_t st) {
     if ((C & 3) || C > 256 * LN_MAXV) return PA2D_ERR_UNSUPPORTED;
+    if (rows <= 0) return PA2D_OK;
     int grid = ceil_div(rows, 4);
     if (grid > 8192) grid = 8192;
     hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid), dim3(256), 0, st, x, g, b, y, mean, rstd, rows, C, eps);
@@ -240,6 +241,7 @@ int pa2d_layernorm_bwd(const float* dy, const float* x, const float* mean, const
                        const float* dres, float* dx, float* dg, float* db, void* ws, size_t ws_bytes, int rows, int C,
                        hipStream_t st) {
     if ((C & 3) || C > 256 * LN_MAXV) return PA2D_ERR_UNSUPPORTED;
+    if (rows <= 0) { const int rz = pa2d_zero(dg, sizeof(float) * C, st); return rz ? rz : pa2d_zero(db, sizeof(float) * C, st); }
     if (ws_bytes < pa2d_layernorm_bwd_workspace(rows, C)) return PA2D_ERR_WORKSPACE;
     const int nb = row_blocks(rows);
     const int rpb = ceil_div(rows, nb);
@@ -260,6 +262,7 @@ int pa2d_layernorm_bwd(const float* dy, const float* x, const float* mean, const
 int pa2d_head_fwd(const float* xn, const float* w, const float* b, float* y, int rows, int C, int out_dim,
                   hipStream_t st) {
     if ((C & 3) || out_dim < 1 || out_dim > 8) return PA2D_ERR_UNSUPPORTED;
+    if (rows <= 0) return PA2D_OK;
     int grid = ceil_div(rows, 4);
     if (grid > 8192) grid = 8192;
     if (out_dim == 1) hipLaunchKernelGGL((head_fwd_kernel<1>), dim3(grid), dim3(256), 0, st, xn, w, b, y, rows, C, out_dim);
@@ -277,6 +280,7 @@ size_t pa2d_head_bwd_workspace(int rows, int C, int out_dim) {
 int pa2d_head_bwd(const float* dy, const float* xn, const float* w, float* dxn, float* dw, float* db, void* ws,
                   size_t ws_bytes, int rows, int C, int out_dim, hipStream_t st) {
     if ((C & 3) || out_dim < 1 || out_dim > 8) return PA2D_ERR_UNSUPPORTED;
+    if (rows <= 0) { const int rz = pa2d_zero(dw, sizeof(float) * out_dim * C, st); return rz ? rz : pa2d_zero(db, sizeof(float) * out_dim, st); }
     if (ws_bytes < pa2d_head_bwd_workspace(rows, C, out_dim)) return PA2D_ERR_WORKSPACE;
     const int rec = out_dim * C + out_dim;
     const size_t smem = sizeof(float) * 4 * rec;
@@ -300,9 +304,9 @@ int pa2d_head_bwd(const float* dy, const float* xn, const float* w, float* dxn, 
 }
 
 int pa2d_act_bwd(const float* dy, const float* pre, float* out, long long n, int act, hipStream_t st) {
+    if (n <= 0) return PA2D_OK;
     long long blocks = ceil_div_ll(n, 256);
     if (blocks > 8192) blocks = 8192;
-    if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, dy, pre, out, n, act);
     PA2D_CHECK_LAUNCH();
     return PA2D_OK;

@@ -675,10 +675,10 @@ extern "C" {
 
 // number of point chunks per (batch, head) and points per chunk used by every slice-stage kernel
 int pa2d_slice_nchunk(int B, int N, int heads) {
-    // enough chunks to fill the CUs at small batch, but at most 16: the token kernel sums the chunk
-    // partials serially per element (64 chunks made it 3x slower than the attention itself at B=2), and
-    // at least 256 points per workgroup keep 4 groups per wave in flight
-    const int bh = B * heads;
+    // enough chunks to fill the CUs at small batch, but at most 16 (the token kernel fetches the chunk
+    // partials of an element 16 at a time) and at least 256 points per workgroup (4 groups per wave in flight)
+    const int bh = B * heads > 0 ? B * heads : 1;
+    if (N < 1) return 1;
     int nchunk = ceil_div(1024, bh);
     int maxc = ceil_div(N, 256);
     if (maxc > 16) maxc = 16;
@@ -695,6 +695,7 @@ int pa2d_slice_scatter(const float* xm, long long ldx, const float* v, long long
                        int heads, int D, int M, int clamp_temperature, hipStream_t st) {
     const int mt = mt_for(M);
     if ((ldx & 3) || (D & 7)) return PA2D_ERR_ARG;
+    if (B <= 0 || N <= 0) return PA2D_OK;
     SliceParams p;
     p.xm = xm; p.ldx = ldx; p.v = v; p.ldv = ldv; p.ws = ws; p.bs = bs; p.temperature = temperature;
     p.spart = spart; p.npart = npart; p.B = B; p.N = N; p.heads = heads; p.M = M; p.clamp = clamp_temperature;
@@ -719,6 +720,7 @@ int pa2d_deslice_fwd(const float* xm, long long ldx, const float* o, const float
                      int clamp_temperature, hipStream_t st) {
     const int mt = mt_for(M);
     if ((ldx & 3) || (ldy & 3) || (D & 7)) return PA2D_ERR_ARG;
+    if (B <= 0 || N <= 0) return PA2D_OK;
     DesliceParams p;
     p.xm = xm; p.ldx = ldx; p.o = o; p.ws = ws; p.bs = bs; p.temperature = temperature; p.y = y; p.ldy = ldy;
     p.B = B; p.N = N; p.heads = heads; p.M = M; p.clamp = clamp_temperature;
@@ -751,6 +753,11 @@ int pa2d_slice_bwd_points(const float* xm, long long ldx, const float* fm, long 
                           int B, int N, int heads, int D, int M, int clamp_temperature, hipStream_t st) {
     const int mt = mt_for(M);
     if ((ldx & 3) || (ldf & 3) || (lddy & 3) || (lddx & 3) || (lddf & 3) || (D & 7)) return PA2D_ERR_ARG;
+    if (B <= 0 || N <= 0) {
+        int rz = pa2d_zero(dws, sizeof(float) * M * D, st);
+        if (!rz) rz = pa2d_zero(dbs, sizeof(float) * M, st);
+        return rz ? rz : pa2d_zero(dtemperature, sizeof(float) * heads, st);
+    }
     if (ws_bytes < pa2d_slice_bwd_workspace(B, N, heads, D, M)) return PA2D_ERR_WORKSPACE;
     SliceBwdParams p;
     p.xm = xm; p.ldx = ldx; p.fm = fm; p.ldf = ldf; p.dy = dy; p.lddy = lddy; p.ws = ws; p.bs = bs;

@@ -284,6 +284,7 @@ int pa2d_token_attn_fwd(const float* spart, const float* npart, const float* wq,
                         float* s, float* nrm, float* o, int BH, int nchunk, int M, int D, hipStream_t st) {
     const size_t smem = pa2d_token_attn_lds_bytes(M, D, 0);
     if (smem > 160 * 1024 || M > 128 || (D & 3)) return PA2D_ERR_UNSUPPORTED;
+    if (BH <= 0) return PA2D_OK;
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&token_attn_fwd_kernel),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
@@ -305,6 +306,12 @@ int pa2d_token_attn_bwd(const float* s, const float* nrm, const float* wq, const
                         size_t ws_bytes, int BH, int nchunk, int M, int D, hipStream_t st) {
     const size_t smem = pa2d_token_attn_lds_bytes(M, D, 1);
     if (smem > 160 * 1024 || M > 128 || (D & 3)) return PA2D_ERR_UNSUPPORTED;
+    if (BH <= 0) {
+        const size_t wb = sizeof(float) * (size_t)D * D;
+        int rz = pa2d_zero(dwq, wb, st);
+        if (!rz) rz = pa2d_zero(dwk, wb, st);
+        return rz ? rz : pa2d_zero(dwv, wb, st);
+    }
     if (ws_bytes < pa2d_token_attn_bwd_workspace(BH, D)) return PA2D_ERR_WORKSPACE;
     if (smem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&token_attn_bwd_kernel),

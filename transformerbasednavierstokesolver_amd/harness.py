@@ -62,17 +62,39 @@ def train_iteration(model, x, fx, yy, step=1, loss_fn=None, fold_time=False):
     return loss, full, pred
 
 
+# widest per-row tensor any kernel addresses through a 32-bit buffer descriptor must stay below 4 GiB
+FOLD_MAX_BYTES = 2 ** 32 - 4096
+
+
+def _fold_group(model, bsz, npoints, ncalls):
+    """How many teacher-forced calls fit in ONE folded model call: the widest activation row ([x_mid | fx_mid] =
+    2C, the preprocess hidden 2C, or the MLP hidden r*C floats) times the folded row count must stay under the
+    4 GiB extent of a buffer descriptor (libpa2d returns PA2D_ERR_UNSUPPORTED beyond it)."""
+    inner = getattr(model, "transolver_model", model)
+    C = inner.n_hidden
+    r = max((blk.mlp.linear_pre[0].weight.shape[0] for blk in inner.blocks), default=C) / C
+    width = int(max(2, r) * C)
+    rows = FOLD_MAX_BYTES // (4 * width)
+    return max(1, min(ncalls, rows // max(1, bsz * npoints)))
+
+
 def _train_iteration_folded(model, x, fx, yy, step, loss_fn):
     T, bsz, F = yy.shape[-1], x.shape[0], fx.shape[-1]
     nt = len(range(0, T, step))
     seq = torch.cat((fx, yy), dim=-1)                                     # frames the windows slide over
-    wins = torch.stack([seq[..., t * step:t * step + F] for t in range(nt)], 0)       # [nt,B,N,F]
-    im = model(x.repeat(nt, 1, 1), fx=wins.reshape(nt * bsz, *fx.shape[1:]))          # [nt*B,N,step]
-    im = im.reshape(nt, bsz, *im.shape[1:])
-    loss = 0
-    for t in range(nt):                       # per-call loss terms, so any reduction mode of loss_fn carries over
-        y = yy[..., t * step:(t + 1) * step]
-        loss = loss + loss_fn(im[t].reshape(bsz, -1), y.reshape(bsz, -1))
+    group = _fold_group(model, bsz, x.shape[1], nt)
+    loss, outs = 0, []
+    for t0 in range(0, nt, group):                                        # normally ONE group
+        g = min(group, nt - t0)
+        wins = torch.stack([seq[..., t * step:t * step + F] for t in range(t0, t0 + g)], 0)       # [g,B,N,F]
+        im = model(x.repeat(g, 1, 1), fx=wins.reshape(g * bsz, *fx.shape[1:]))                    # [g*B,N,step]
+        im = im.reshape(g, bsz, *im.shape[1:])
+        for k in range(g):                    # per-call loss terms, so any reduction mode of loss_fn carries over
+            t = t0 + k
+            y = yy[..., t * step:(t + 1) * step]
+            loss = loss + loss_fn(im[k].reshape(bsz, -1), y.reshape(bsz, -1))
+        outs.append(im)
+    im = torch.cat(outs, 0) if len(outs) > 1 else outs[0]
     pred = im.permute(1, 2, 0, 3).reshape(bsz, im.shape[2], -1)
     with torch.no_grad():
         full = loss_fn(pred.reshape(bsz, -1), yy.reshape(bsz, -1))
