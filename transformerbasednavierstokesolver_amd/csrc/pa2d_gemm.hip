@@ -94,6 +94,8 @@ __device__ __forceinline__ void kc_epilogue(const KCParams& p, f32x16 (&acc)[TM]
         if (has_res) { KC_EPI(true, false, false, false, 0) } else { KC_EPI(false, false, false, false, 0) }
     } else if (p.epi == (EPI_ACT | EPI_STORE_PRE) && gelu && !has_res) {
         KC_EPI(false, true, true, false, ACT_GELU)
+    } else if (p.epi == EPI_ACT && gelu && !has_res) {          // inference: no pre-activation saved
+        KC_EPI(false, false, true, false, ACT_GELU)
     } else if (p.epi == EPI_MUL_DACT && gelu && !has_res) {
         KC_EPI(false, false, false, true, ACT_GELU)
     } else {   // generic: any flag combination / activation (off the hot path)

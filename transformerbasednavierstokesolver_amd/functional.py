@@ -86,8 +86,9 @@ class PhysicsAttentionFn(Function):
 
 
 # ------------------------------------------------------------------------------ MLP (Linear-act-Linear)
-def mlp_forward(x2d, w1, b1, w2, b2, act, res2d):
-    hact, hpre = ops.linear_fwd(x2d, w1, b1, act=act, want_pre=True)
+def mlp_forward(x2d, w1, b1, w2, b2, act, res2d, need_bwd=True):
+    """need_bwd=False (inference): the pre-activation is not written (one [rows, r*C] store less)."""
+    hact, hpre = ops.linear_fwd(x2d, w1, b1, act=act, want_pre=need_bwd)
     out, _ = ops.linear_fwd(hact, w2, b2, res=res2d)
     return out, (x2d, hpre, hact)
 
@@ -110,7 +111,7 @@ class MLPFn(Function):
         x2d = x.detach().reshape(-1, shp[-1]).contiguous()
         w1, b1, w2, b2 = (t.detach().contiguous() for t in (w1, b1, w2, b2))
         res2d = None if res is None else res.detach().reshape(-1, w2.shape[0]).contiguous()
-        out, saved = mlp_forward(x2d, w1, b1, w2, b2, act, res2d)
+        out, saved = mlp_forward(x2d, w1, b1, w2, b2, act, res2d, need_bwd=any(ctx.needs_input_grad))
         ctx.saved, ctx.w, ctx.act, ctx.shp, ctx.has_res = saved, (w1, w2), act, shp, res is not None
         return out.view(*shp[:-1], w2.shape[0])
 
@@ -192,7 +193,7 @@ class MLPBranchFn(Function):
         fx2d = fx.detach().reshape(-1, shp[-1]).contiguous()
         ln_w, ln_b, w1, b1, w2, b2 = (t.detach().contiguous() for t in (ln_w, ln_b, w1, b1, w2, b2))
         xn, mean, rstd = ops.layernorm_fwd(fx2d, ln_w, ln_b)
-        out, saved = mlp_forward(xn, w1, b1, w2, b2, act, fx2d)
+        out, saved = mlp_forward(xn, w1, b1, w2, b2, act, fx2d, need_bwd=any(ctx.needs_input_grad))
         ctx.saved, ctx.w, ctx.act, ctx.ln = saved, (w1, w2), act, (fx2d, mean, rstd, ln_w)
         return out.view(shp)
 
