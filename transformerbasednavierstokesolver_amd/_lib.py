@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libpa2d.so")
+LIB_PATH = os.environ.get("PA2D_LIB") or os.path.join(_HERE, "csrc", "libpa2d.so")   # PA2D_LIB: A/B builds
 
 _f = C.c_void_p      # const float* / float* (device pointers travel as integers)
 _i = C.c_int
