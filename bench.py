@@ -114,6 +114,7 @@ def main():
     ap.add_argument("--fold-time", action="store_true",
                     help="run the 10 teacher-forced calls of an iteration as ONE call on 10*B windows (same loss and gradients)")
     ap.add_argument("--no-folded-leg", action="store_true", help="skip the secondary time-folded measurement")
+    ap.add_argument("--no-split-leg", action="store_true", help="skip the secondary split-engine measurement")
     ap.add_argument("--torch-optim", action="store_true", help="torch.optim.AdamW + torch rel-L2 instead of the fused kernels")
     ap.add_argument("--gemm-mode", type=int, default=0,
                     help="0 = exact fp32 MFMA (the metric of record), 2 = bf16-compute mode (BASELINE configs[2] numerics)")
@@ -152,7 +153,7 @@ def main():
     else:   # fused multi-tensor AdamW + fused rel-L2 (libpa2d), same arithmetic
         opt = FusedAdamW(model.parameters(), lr=1e-3, weight_decay=1e-5)
         loss_fn = FusedTestLoss(size_average=False)
-    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-3, total_steps=2 * max(total_steps, 2) + 4)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-3, total_steps=3 * max(total_steps, 2) + 6)
     log(f"rank {rank}/{world}: model built, generating {B} synthetic trajectories")
     pos, a, u = synth.ns_batch(B, seed=100 + rank)    # this rank's shard of the global batch
     x, fx, yy = (torch.from_numpy(t).to(dev) for t in (pos, a, u))
@@ -262,6 +263,38 @@ def main():
                               "ms_per_step": round(1e3 * fd / args.steps, 2),
                               "note": "10 teacher-forced calls run as one call on 10*B windows (caller-side change)"}
         log(f"time-folded leg: {out['time_folded']['value']} samples/s")
+
+    if args.gemm_mode == 0 and not (args.fold_time or args.graph or args.no_split_leg):
+        # Secondary leg, reported next to (never instead of) `value`: the same sequential iteration with the conv
+        # GEMMs on the fp32-accurate 6-term bf16-split engine (pa2d_set_gemm_mode(1); passes the same fp32 parity
+        # tolerances, tests/test_gpu_model.py::test_split_engine_full_ns_model_meets_fp32_tolerances).
+        lib = _lib.load()
+        lib.pa2d_set_gemm_mode(1)
+        try:
+            def sstep():
+                return harness.train_step(model, opt, sched, x, fx, yy, grad_sync=sync, loss_fn=loss_fn)
+            sstep()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                sstep()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            sd_ = time.perf_counter() - t1
+        finally:
+            lib.pa2d_set_gemm_mode(0)
+        if world > 1:
+            ts_ = torch.tensor([sd_], device=dev, dtype=torch.float64)
+            dist.all_reduce(ts_, op=dist.ReduceOp.MAX)
+            sd_ = float(ts_.item())
+        out["fp32_split_engine"] = {"value": round(world * B * args.steps / sd_, 4), "unit": "samples/s",
+                                    "ms_per_step": round(1e3 * sd_ / args.steps, 2),
+                                    "note": "conv GEMMs as 6 bf16 MFMA terms of an exact hi+mid+lo operand split, fp32 "
+                                            "accumulate (fp32-level accuracy); opt-in engine, not the metric of record"}
+        log(f"split-engine leg: {out['fp32_split_engine']['value']} samples/s")
 
     if not args.no_rollout:
         # unrolled-inference steps/s (ns_vorticity_unrolling.py:264-286), hipGraph-captured step.  Replicas

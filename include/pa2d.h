@@ -77,7 +77,8 @@ int pa2d_gemm_bwd_weight(const float* dy, long long lddy, const float* x, long l
  * ev_start / ev_stop: optional hipEvent_t (NULL = none) recorded on `stream` immediately around the
  * implicit-GEMM launch (forward: the [B*N,9C]x[9C,2C] product; backward: the data-gradient product),
  * so a benchmark can time that kernel alone without a profiler. */
-size_t pa2d_conv3x3x2_workspace(int B, int H, int W, int C);
+size_t pa2d_conv3x3x2_workspace(int B, int H, int W, int C);       /* backward */
+size_t pa2d_conv3x3x2_fwd_workspace(int B, int H, int W, int C);   /* forward  */
 /* Packed weights.  The implicit GEMM reads the two [C,C,3,3] kernels from a K-major pack whose layout depends on
  * the tile / K-step chosen for (B,H,W,C) and on the GEMM mode.  By default fwd/bwd build it per call into `ws`
  * (weights change every optimizer step).  A caller that knows the weights are constant over several calls (the

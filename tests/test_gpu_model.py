@@ -409,3 +409,16 @@ def test_c_abi_error_codes_on_device():
         ops.linear_fwd(t.view(64, 64).t(), t.view(64, 64))
     with pytest.raises(RuntimeError, match="GPU"):
         ops.linear_fwd(torch.zeros(4, 4), torch.zeros(4, 4))
+
+
+def test_split_engine_full_ns_model_meets_fp32_tolerances():
+    """pa2d_set_gemm_mode(1): every conv GEMM (forward, data gradient, weight gradient) on the 6-term bf16-split
+    engine with pre-split activation planes — the full BASELINE configs[1] model must pass the G5 fixture with
+    the SAME fp32 tolerances as the exact engine."""
+    from transformerbasednavierstokesolver_amd import _lib
+    lib = _lib.load()
+    lib.pa2d_set_gemm_mode(1)
+    try:
+        test_g5_full_ns_config_forward_backward()
+    finally:
+        lib.pa2d_set_gemm_mode(0)

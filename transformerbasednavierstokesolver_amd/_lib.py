@@ -31,6 +31,7 @@ SIGNATURES = {
     "pa2d_gemm_bwd_weight_workspace": (_sz, [_i, _i, _i]),
     "pa2d_gemm_bwd_weight": (_i, [_f, _ll, _f, _ll, _f, _f, _f, _sz, _i, _i, _i, _st]),
     "pa2d_conv3x3x2_workspace": (_sz, [_i, _i, _i, _i]),
+    "pa2d_conv3x3x2_fwd_workspace": (_sz, [_i, _i, _i, _i]),
     "pa2d_conv3x3x2_pack_bytes": (_sz, [_i]),
     "pa2d_conv3x3x2_pack": (_i, [_f, _f, _f, _sz, _i, _i, _i, _i, _i, _st]),
     "pa2d_conv3x3x2_fwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _i, _st, _st, _st]),

@@ -43,6 +43,7 @@ struct KCParams {
     int H, W, Cin;   // im2col view: A = image [B,H,W,Cin] with pixel pitch lda, K = 9*Cin
     unsigned a_bytes, b_bytes;   // extents of A and B for the buffer descriptors (filled by launch_kc)
     unsigned c_bytes, res_bytes, aux_bytes;
+    int apre;   // split engine: A already holds the NT bf16 planes of every 32-channel chunk (split_planes_kernel)
 };
 
 __device__ __forceinline__ float gelu_f(float x) { return gelu_exact(x); }
@@ -271,7 +272,10 @@ __device__ __forceinline__ void split3(const float4 v, bf16x4& hi, bf16x4& mid, 
 // One __syncthreads per K-step hands stage (k+1)&1 over and frees stage k&1.
 // NT = 3: the 6-term fp32-accuracy split above.  NT = 1: plain bf16 compute (operands rounded to bf16,
 // ONE MFMA term, fp32 accumulate) — the autocast-style numerics of BASELINE configs[2]/[4].
-template <int BM, int BN, bool IM2COL, int NT>
+// APRE: the A operand arrives pre-split as well ([pixel][32-channel chunk][plane][32] bf16, made once per tensor by
+// split_planes_kernel), so BOTH tiles are staged with 16-byte copies and the producers do no conversion work:
+// each activation element is converted once instead of once per (tap, column tile) = 36 times.
+template <int BM, int BN, bool IM2COL, int NT, bool APRE = false>
 __global__ __launch_bounds__(512, 2) void gemm_kc_split_kernel(const KCParams p) {
     constexpr int BK = 32, PITCHB = NT * 64 + 16;        // bytes per LDS row (NT planes x 64 B + 16): 208 / 80
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
@@ -300,8 +304,22 @@ __global__ __launch_bounds__(512, 2) void gemm_kc_split_kernel(const KCParams p)
         constexpr bool PRESPLIT = IM2COL;
         constexpr int PIECES = NT * 4;                            // 16-byte pieces per row and K-step
         constexpr int BP_IT = (BN * PIECES) / 256;                // pieces per producer thread
+        constexpr int AP_IT = (BM * PIECES) / 256;                // A pieces per producer thread (APRE)
         unsigned a_off[A_IT], b_off[B_IT], bp_off[BP_IT], bp_lds[BP_IT];
         int a_y[A_IT], a_x[A_IT];
+        unsigned ap_off[AP_IT], ap_lds[AP_IT];
+        int ap_y[AP_IT], ap_x[AP_IT];
+        const int nch_in = p.Cin / 32;                            // 32-channel chunks per pixel (APRE)
+#pragma unroll
+        for (int s = 0; s < AP_IT; ++s) {
+            const int q = ptid + 256 * s, row = q / PIECES, piece = q - row * PIECES;
+            const int gm = tile_m * BM + row;
+            ap_off[s] = (APRE && gm < p.M) ? ((unsigned)gm * (unsigned)(nch_in * PIECES) + piece) * 16u : OOB_OFF;
+            ap_lds[s] = row * PITCHB + piece * 16;
+            const int n = APRE ? gm % (p.H * p.W) : 0;
+            ap_y[s] = n / p.W;
+            ap_x[s] = n - ap_y[s] * p.W;
+        }
 #pragma unroll
         for (int s = 0; s < A_IT; ++s) {
             const int gm = tile_m * BM + lr + 32 * s;
@@ -328,12 +346,21 @@ __global__ __launch_bounds__(512, 2) void gemm_kc_split_kernel(const KCParams p)
         }
         // two register sets: K-step c lives in set c&1 and is loaded two barriers before it is stored
         float4 ra0[A_IT], ra1[A_IT], rb0[B_IT], rb1[B_IT];
-        u32x4 rp0[BP_IT], rp1[BP_IT];
-#define KS_LOAD(kc_, RA, RB, RP)                                                                       \
+        u32x4 rp0[BP_IT], rp1[BP_IT], rq0[AP_IT], rq1[AP_IT];
+#define KS_LOAD(kc_, RA, RB, RP, RQ)                                                                   \
     {                                                                                                  \
         const int k0_ = (kc_) * BK;                                                                    \
         const bool kin_ = k0_ + lq * 4 < p.K;                                                          \
-        if (IM2COL) {                                                                                  \
+        if (APRE) {                                                                                    \
+            const int cic_ = (kc_) / 9, tap_ = (kc_) - cic_ * 9;                                       \
+            const int dy_ = tap_ / 3 - 1, dx_ = tap_ - (tap_ / 3) * 3 - 1;                             \
+            const int sh_ = ((dy_ * p.W + dx_) * nch_in + cic_) * (PIECES * 16);                       \
+            _Pragma("unroll") for (int s = 0; s < AP_IT; ++s) {                                        \
+                const bool ok_ = (unsigned)(ap_y[s] + dy_) < (unsigned)p.H &&                          \
+                                 (unsigned)(ap_x[s] + dx_) < (unsigned)p.W && ap_off[s] != OOB_OFF;    \
+                RQ[s] = __builtin_amdgcn_raw_buffer_load_b128(ra_rsrc, ok_ ? ap_off[s] + (unsigned)sh_ : OOB_OFF, 0, 0); \
+            }                                                                                          \
+        } else if (IM2COL) {                                                                                  \
             const int cic_ = (kc_) / 9, tap_ = (kc_) - cic_ * 9;                                       \
             const int dy_ = tap_ / 3 - 1, dx_ = tap_ - (tap_ / 3) * 3 - 1;                             \
             const int sh_ = ((dy_ * p.W + dx_) * (int)p.lda + cic_ * BK) * 4;                          \
@@ -355,18 +382,23 @@ __global__ __launch_bounds__(512, 2) void gemm_kc_split_kernel(const KCParams p)
                 RB[s] = buf_load4(rb_rsrc, (kin_ && b_off[s] != OOB_OFF) ? b_off[s] + k0_ * 4u : OOB_OFF); \
         }                                                                                              \
     }
-#define KS_STORE(buf_, RA, RB, RP)                                                                     \
+#define KS_STORE(buf_, RA, RB, RP, RQ)                                                                 \
     {                                                                                                  \
         unsigned char* const As_ = smem + (buf_) * STAGE;                                              \
         unsigned char* const Bs_ = As_ + BM * PITCHB;                                                  \
-        _Pragma("unroll") for (int s = 0; s < A_IT; ++s) {                                             \
-            bf16x4 h_, m_, l_;                                                                         \
-            split3(RA[s], h_, m_, l_);                                                                 \
-            unsigned char* d_ = As_ + (lr + 32 * s) * PITCHB + lq * 8;                                 \
-            *reinterpret_cast<bf16x4*>(d_) = h_;                                                       \
-            if (NT == 3) {                                                                             \
-                *reinterpret_cast<bf16x4*>(d_ + 64) = m_;                                              \
-                *reinterpret_cast<bf16x4*>(d_ + 128) = l_;                                             \
+        if (APRE) {                                                                                    \
+            _Pragma("unroll") for (int s = 0; s < AP_IT; ++s)                                          \
+                *reinterpret_cast<u32x4*>(As_ + ap_lds[s]) = RQ[s];                                    \
+        } else {                                                                                       \
+            _Pragma("unroll") for (int s = 0; s < A_IT; ++s) {                                         \
+                bf16x4 h_, m_, l_;                                                                     \
+                split3(RA[s], h_, m_, l_);                                                             \
+                unsigned char* d_ = As_ + (lr + 32 * s) * PITCHB + lq * 8;                             \
+                *reinterpret_cast<bf16x4*>(d_) = h_;                                                   \
+                if (NT == 3) {                                                                         \
+                    *reinterpret_cast<bf16x4*>(d_ + 64) = m_;                                          \
+                    *reinterpret_cast<bf16x4*>(d_ + 128) = l_;                                         \
+                }                                                                                      \
             }                                                                                          \
         }                                                                                              \
         if (PRESPLIT) {                                                                                \
@@ -385,21 +417,21 @@ __global__ __launch_bounds__(512, 2) void gemm_kc_split_kernel(const KCParams p)
             }                                                                                          \
         }                                                                                              \
     }
-        KS_LOAD(0, ra0, rb0, rp0)
-        if (nk > 1) KS_LOAD(1, ra1, rb1, rp1)
-        KS_STORE(0, ra0, rb0, rp0)
-        if (nk > 2) KS_LOAD(2, ra0, rb0, rp0)
+        KS_LOAD(0, ra0, rb0, rp0, rq0)
+        if (nk > 1) KS_LOAD(1, ra1, rb1, rp1, rq1)
+        KS_STORE(0, ra0, rb0, rp0, rq0)
+        if (nk > 2) KS_LOAD(2, ra0, rb0, rp0, rq0)
         __syncthreads();
         for (int kc = 0; kc < nk; kc += 2) {
             if (kc + 1 < nk) {                               // K-step kc+1 lives in set 1
-                KS_STORE((kc + 1) & 1, ra1, rb1, rp1)
-                if (kc + 3 < nk) KS_LOAD(kc + 3, ra1, rb1, rp1)
+                KS_STORE((kc + 1) & 1, ra1, rb1, rp1, rq1)
+                if (kc + 3 < nk) KS_LOAD(kc + 3, ra1, rb1, rp1, rq1)
             }
             __syncthreads();
             if (kc + 1 < nk) {
                 if (kc + 2 < nk) {                           // K-step kc+2 lives in set 0
-                    KS_STORE((kc + 2) & 1, ra0, rb0, rp0)
-                    if (kc + 4 < nk) KS_LOAD(kc + 4, ra0, rb0, rp0)
+                    KS_STORE((kc + 2) & 1, ra0, rb0, rp0, rq0)
+                    if (kc + 4 < nk) KS_LOAD(kc + 4, ra0, rb0, rp0, rq0)
                 }
                 __syncthreads();
             }
@@ -531,7 +563,14 @@ static int launch_kc(const KCParams& p_in, bool im2col, hipStream_t st, hipEvent
     const int tiles_m = ceil_div(p.M, 128);
     if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return PA2D_ERR_ARG;
     if (use_split(p.N, im2col, p.Cin)) {
-        if (im2col) p.b_bytes = (unsigned)((size_t)p.N * (p.K / 32) * (gemm_mode() == 2 ? 1 : 3) * 64);
+        const int planes = gemm_mode() == 2 ? 1 : 3;
+        if (im2col) p.b_bytes = (unsigned)((size_t)p.N * (p.K / 32) * planes * 64);
+        if (p.apre) {
+            if (!im2col) return PA2D_ERR_ARG;
+            const unsigned long long pb = (unsigned long long)p.M * (p.Cin / 32) * planes * 64;
+            if (pb >= 0xFFFFFFF0ull) return PA2D_ERR_UNSUPPORTED;
+            p.a_bytes = (unsigned)pb;
+        }
         const int tiles_n = ceil_div(p.N, 128);
         const dim3 grid(ceil_div(tiles_m, 8) * 8 * tiles_n);
         const bool bf = gemm_mode() == 2;
@@ -543,10 +582,16 @@ static int launch_kc(const KCParams& p_in, bool im2col, hipStream_t st, hipEvent
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, big);
             hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kc_split_kernel<128, 128, false, 3>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            hipError_t e3 = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kc_split_kernel<128, 128, true, 3, true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, big);
+            if (e1 == hipSuccess) e1 = e3;
             if (e1 != hipSuccess || e2 != hipSuccess) return (int)(e1 != hipSuccess ? e1 : e2);
             attr_done = true;
         }
-        if (bf) {
+        if (p.apre) {
+            if (bf) hipLaunchKernelGGL((gemm_kc_split_kernel<128, 128, true, 1, true>), grid, dim3(512), smem, st, p);
+            else hipLaunchKernelGGL((gemm_kc_split_kernel<128, 128, true, 3, true>), grid, dim3(512), smem, st, p);
+        } else if (bf) {
             if (im2col) hipLaunchKernelGGL((gemm_kc_split_kernel<128, 128, true, 1>), grid, dim3(512), smem, st, p);
             else hipLaunchKernelGGL((gemm_kc_split_kernel<128, 128, false, 1>), grid, dim3(512), smem, st, p);
         } else {
@@ -587,10 +632,23 @@ struct MCParams {
     unsigned a_bytes, b_bytes;
 };
 
-// BF16 = true: same staging (fp32 tiles [16 rows m][BM]), but each lane gathers its 8 consecutive m of
-// one column with 8 ds_read_b32, rounds them to bf16 and issues ONE v_mfma_f32_32x32x16_bf16 per tile
-// and 16-row chunk instead of 8 fp32 MFMAs (bf16-compute mode).
-template <int BM, int BN, bool IM2COL, bool BF16, int BK = 16>
+// NT = 1: same staging (fp32 tiles [16 rows m][BM]), but each lane gathers its 8 consecutive m of one column
+// with 8 ds_read_b32, rounds them to bf16 and issues ONE v_mfma_f32_32x32x16_bf16 per tile and 16-row chunk
+// instead of 8 fp32 MFMAs (bf16-compute mode).  NT = 3: the gathered values are split exactly into hi+mid+lo
+// bf16 terms in registers and the six products of order <= 2 are accumulated (fp32 accuracy, see
+// gemm_kc_split_kernel): 6 bf16 MFMAs (192 cycles) instead of 8 fp32 MFMAs (512 cycles).  NT = 0: exact fp32.
+template <int NT>
+__device__ __forceinline__ void mc_split_elem(float v, bf16x8 (&pl)[NT], int e) {
+    const __bf16 h = (__bf16)v;
+    pl[0][e] = h;
+    if constexpr (NT == 3) {
+        const float r1 = v - (float)h;
+        const __bf16 m = (__bf16)r1;
+        pl[1][e] = m;
+        pl[2][e] = (__bf16)(r1 - (float)m);
+    }
+}
+template <int BM, int BN, bool IM2COL, int NT, int BK = 16>
 __global__ __launch_bounds__(256, 2) void gemm_mc_kernel(const MCParams p) {
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int A_TPR = BM / 4, A_RPP = 256 / A_TPR, A_IT = BK / A_RPP;
@@ -695,23 +753,31 @@ __global__ __launch_bounds__(256, 2) void gemm_mc_kernel(const MCParams p) {
         if (c + 1 < c_end) MC_LOAD(c + 1)
         const float* a_s = As + buf * BK * BM + kh * BM + wm * WM + li;
         const float* b_s = Bs + buf * BK * BN + kh * BN + wn * WN + li;
-        if constexpr (BF16) {
+        if constexpr (NT > 0) {
             const float* a8 = As + buf * BK * BM + kh * 8 * BM + wm * WM + li;
             const float* b8 = Bs + buf * BK * BN + kh * 8 * BN + wn * WN + li;
-            bf16x8 af[TM], bf[TN];
+            bf16x8 af[TM][NT], bf[TN][NT];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) af[i][e] = (__bf16)a8[e * BM + i * 32];
+                for (int e = 0; e < 8; ++e) mc_split_elem<NT>(a8[e * BM + i * 32], af[i], e);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) bf[j][e] = (__bf16)b8[e * BN + j * 32];
+                for (int e = 0; e < 8; ++e) mc_split_elem<NT>(b8[e * BN + j * 32], bf[j], e);
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (NT == 3) {   // smallest terms first
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+                }
         } else {
         // fragments of k-step kk+1 are fetched into the other register set before the MFMAs of
         // k-step kk issue, so the LDS latency hides behind 4 x 64 MFMA cycles
@@ -862,17 +928,19 @@ static int launch_mc(const float* A, long long lda, int Mi, const float* B, long
     static int mc_bk = -1;
     if (mc_bk < 0) { const char* e = getenv("PA2D_MC_BK"); mc_bk = (e && atoi(e) == 32) ? 32 : 16; }
     if (pl.big && !bf && mc_bk == 32 && (pl.chunks_per_split % 2) == 0) {
-        if (im2col) hipLaunchKernelGGL((gemm_mc_kernel<128, 128, true, false, 32>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((gemm_mc_kernel<128, 128, false, false, 32>), grid, dim3(256), 0, st, p);
+        if (im2col) hipLaunchKernelGGL((gemm_mc_kernel<128, 128, true, 0, 32>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_mc_kernel<128, 128, false, 0, 32>), grid, dim3(256), 0, st, p);
+    } else if (pl.big && im2col && gemm_mode() == 1 && (Cin % 32) == 0) {     // 6-term split, fp32 accuracy
+        hipLaunchKernelGGL((gemm_mc_kernel<128, 128, true, 3>), grid, dim3(256), 0, st, p);
     } else if (pl.big && bf) {
-        if (im2col) hipLaunchKernelGGL((gemm_mc_kernel<128, 128, true, true>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((gemm_mc_kernel<128, 128, false, true>), grid, dim3(256), 0, st, p);
+        if (im2col) hipLaunchKernelGGL((gemm_mc_kernel<128, 128, true, 1>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_mc_kernel<128, 128, false, 1>), grid, dim3(256), 0, st, p);
     } else if (pl.big) {
-        if (im2col) hipLaunchKernelGGL((gemm_mc_kernel<128, 128, true, false>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((gemm_mc_kernel<128, 128, false, false>), grid, dim3(256), 0, st, p);
+        if (im2col) hipLaunchKernelGGL((gemm_mc_kernel<128, 128, true, 0>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_mc_kernel<128, 128, false, 0>), grid, dim3(256), 0, st, p);
     } else {
-        if (im2col) hipLaunchKernelGGL((gemm_mc_kernel<64, 64, true, false>), grid, dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((gemm_mc_kernel<64, 64, false, false>), grid, dim3(256), 0, st, p);
+        if (im2col) hipLaunchKernelGGL((gemm_mc_kernel<64, 64, true, 0>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((gemm_mc_kernel<64, 64, false, 0>), grid, dim3(256), 0, st, p);
     }
     PA2D_CHECK_LAUNCH();
     return PA2D_OK;
@@ -956,6 +1024,35 @@ __global__ void repack_kernel(const float* __restrict__ w0, const float* __restr
         const float* src = co < C ? w0 : w1;
         dst[idx] = src[((size_t)(co % C) * Cin + ci) * 9 + (8 - tap)];
     }
+}
+
+// Activation pre-split for the bf16 engines: src [rows][ld >= C] fp32 -> dst [rows][C/32][NT][32] bf16 (NT = 3:
+// hi | mid | lo with x = hi + mid + lo up to 2^-25 |x|; NT = 1: x rounded to bf16).  One thread per 4 channels.
+__global__ void split_planes_kernel(const float* __restrict__ src, long long ld, __bf16* __restrict__ dst,
+                                    long long rows, int C, int NT) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int q4 = C / 4;
+    if (idx >= rows * q4) return;
+    const long long row = idx / q4;
+    const int c4 = (int)(idx - row * q4), chunk = c4 >> 3, q = c4 & 7;
+    const float4 v = *reinterpret_cast<const float4*>(src + row * ld + c4 * 4);
+    bf16x4 h, m, l;
+    split3(v, h, m, l);
+    __bf16* d = dst + ((row * (C / 32) + chunk) * NT) * 32 + q * 4;
+    *reinterpret_cast<bf16x4*>(d) = h;
+    if (NT == 3) {
+        *reinterpret_cast<bf16x4*>(d + 32) = m;
+        *reinterpret_cast<bf16x4*>(d + 64) = l;
+    }
+}
+static size_t planes_bytes(long long rows, int C, int NT) { return (size_t)rows * C * NT * 2; }
+static int launch_split_planes(const float* src, long long ld, void* dst, long long rows, int C, int NT, hipStream_t st) {
+    if (C & 31) return PA2D_ERR_UNSUPPORTED;
+    const long long n = rows * (C / 4);
+    hipLaunchKernelGGL(split_planes_kernel, dim3((unsigned)ceil_div_ll(n, 256)), dim3(256), 0, st, src, ld, (__bf16*)dst,
+                       rows, C, NT);
+    PA2D_CHECK_LAUNCH();
+    return PA2D_OK;
 }
 
 // conv weight pack for the bf16 engines: dst row n = [K-step kc = cic*9+tap][plane][32 channels] bf16,
@@ -1061,11 +1158,26 @@ int pa2d_gemm_bwd_weight(const float* dy, long long lddy, const float* x, long l
     return rc;
 }
 
+// bf16 engines: bytes of the pre-split activation planes of a [rows, Cin] operand (0 when the engine selected for
+// this GEMM reads fp32 operands)
+static size_t conv_planes_bytes(int M, int N, int Cin) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("PA2D_SPLIT_APRE"); on = e ? atoi(e) : 1; }
+    if (!on || !use_split(N, true, Cin)) return 0;
+    return (planes_bytes(M, Cin, gemm_mode() == 2 ? 1 : 3) + 255) & ~(size_t)255;
+}
+
+// backward workspace: [weight pack | slabs or column-sum partials | activation planes (bf16 engines)]
 size_t pa2d_conv3x3x2_workspace(int B, int H, int W, int C) {
     const size_t pack = (size_t)3 * C * 9 * C;      // fp32 pack (2C*9C floats) or 3 bf16 planes (1.5x)
     const MCPlan pl = plan_mc(2 * C, 9 * C, B * H * W);
     size_t sl = pl.slab_floats, cs = (size_t)colsum_blocks(B * H * W) * 2 * C;
-    return (pack + (sl > cs ? sl : cs)) * sizeof(float);
+    return (pack + (sl > cs ? sl : cs)) * sizeof(float) + conv_planes_bytes(B * H * W, C, 2 * C);
+}
+
+// forward workspace: [weight pack (unused if prepacked) | activation planes (bf16 engines)]
+size_t pa2d_conv3x3x2_fwd_workspace(int B, int H, int W, int C) {
+    return (size_t)3 * C * 9 * C * sizeof(float) + conv_planes_bytes(B * H * W, 2 * C, C);
 }
 
 // Packed conv weights in the layout the engine selected for these dims wants (channel chunk = K-step of the
@@ -1099,15 +1211,22 @@ int pa2d_conv3x3x2_fwd(const float* xn, const float* wx, const float* bx, const 
                        float* out, const void* prepacked, void* ws, size_t ws_bytes, int B, int H, int W, int C,
                        hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (B <= 0) return PA2D_OK;
+    if (ws_bytes < pa2d_conv3x3x2_fwd_workspace(B, H, W, C)) return PA2D_ERR_WORKSPACE;
     const float* pack = (const float*)prepacked;
     if (!pack) {
-        if (ws_bytes < pa2d_conv3x3x2_pack_bytes(C)) return PA2D_ERR_WORKSPACE;
         const int rc = conv_pack(wx, wf, (float*)ws, B * H * W, C, 0, st);
         if (rc) return rc;
         pack = (const float*)ws;
     }
+    const size_t apl = conv_planes_bytes(B * H * W, 2 * C, C);
+    void* const planes = (char*)ws + pa2d_conv3x3x2_pack_bytes(C);
+    if (apl) {
+        const int rc = launch_split_planes(xn, C, planes, (long long)B * H * W, C, gemm_mode() == 2 ? 1 : 3, st);
+        if (rc) return rc;
+    }
     KCParams p = {};
-    p.A = xn; p.lda = C; p.B = pack; p.ldb = 9 * C; p.C = out; p.ldc = 2 * C;
+    p.A = apl ? (const float*)planes : xn; p.apre = apl ? 1 : 0;
+    p.lda = C; p.B = pack; p.ldb = 9 * C; p.C = out; p.ldc = 2 * C;
     p.bias = bx; p.bias2 = bf; p.bias_split = C;
     p.M = B * H * W; p.N = 2 * C; p.K = 9 * C; p.H = H; p.W = W; p.Cin = C;
     return launch_kc(p, true, st, ev_start, ev_stop);
@@ -1135,8 +1254,15 @@ int pa2d_conv3x3x2_bwd(const float* dout, const float* xn, const float* wx, cons
             if (rc) return rc;
             pack = (const float*)ws;
         }
+        const size_t apl = conv_planes_bytes(M, C, 2 * C);
+        void* const planes = (char*)ws + pa2d_conv3x3x2_workspace(B, H, W, C) - apl;
+        if (apl) {
+            rc = launch_split_planes(dout, 2 * C, planes, M, 2 * C, gemm_mode() == 2 ? 1 : 3, st);
+            if (rc) return rc;
+        }
         KCParams p = {};
-        p.A = dout; p.lda = 2 * C; p.B = pack; p.ldb = 9 * 2 * C; p.C = dxn; p.ldc = C;
+        p.A = apl ? (const float*)planes : dout; p.apre = apl ? 1 : 0;
+        p.lda = 2 * C; p.B = pack; p.ldb = 9 * 2 * C; p.C = dxn; p.ldc = C;
         p.M = M; p.N = C; p.K = 9 * 2 * C; p.H = H; p.W = W; p.Cin = 2 * C;
         rc = launch_kc(p, true, st, ev_start, ev_stop);
         if (rc) return rc;

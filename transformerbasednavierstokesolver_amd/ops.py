@@ -169,7 +169,7 @@ def conv3x3x2_fwd(xn, wx, bx, wf, bf, H, W):
     B, N, Cc = xn.shape
     out = torch.empty(B, N, 2 * Cc, dtype=torch.float32, device=xn.device)
     pre = _conv_pack(wx, wf, B, H, W, Cc, 0)
-    nb = 0 if pre else _L().pa2d_conv3x3x2_pack_bytes(Cc)
+    nb = _L().pa2d_conv3x3x2_fwd_workspace(B, H, W, Cc)
     ws = _ws(nb, xn)
     e0, e1 = _conv_events()
     _lib.check(_L().pa2d_conv3x3x2_fwd(_p(xn), _p(wx), _p(bx), _p(wf), _p(bf), _p(out), pre, ws.data_ptr(), nb,
