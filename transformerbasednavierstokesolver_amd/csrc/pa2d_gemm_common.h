@@ -1,0 +1,138 @@
+// Internal declarations shared by the GEMM translation units of libpa2d (pa2d_gemm.hip = engine selection + C ABI,
+// pa2d_gemm_kc.hip = exact fp32 engine, pa2d_gemm_split.hip = bf16 split / bf16 compute engines,
+// pa2d_gemm_mc.hip = weight-gradient engine and the deterministic reductions).  Split only so that the
+// translation units compile in parallel; nothing here is part of the C ABI.
+#pragma once
+#include "pa2d_internal.h"
+#include <stdlib.h>
+
+#define EPI_ACT 1        // out = act(acc + bias)
+#define EPI_STORE_PRE 2  // aux = acc + bias   (pre-activation, saved for backward)
+#define EPI_MUL_DACT 4   // out = acc * act'(aux)
+
+struct KCParams {
+    const float* A; long long lda;
+    const float* B; long long ldb;
+    float* C; long long ldc;
+    const float* bias;
+    const float* bias2; int bias_split;   // columns >= bias_split take bias2[col - bias_split] (two stacked projections)
+    const float* res; long long ldres;
+    float* aux; long long ldaux;
+    int M, N, K;
+    int act, epi;
+    int H, W, Cin;   // im2col view: A = image [B,H,W,Cin] with pixel pitch lda, K = 9*Cin
+    unsigned a_bytes, b_bytes;   // extents of A and B for the buffer descriptors (filled by launch_kc)
+    unsigned c_bytes, res_bytes, aux_bytes;
+    int apre;   // split engine: A already holds the NT bf16 planes of every 32-channel chunk (split_planes_kernel)
+};
+
+__device__ __forceinline__ float gelu_f(float x) { return gelu_exact(x); }
+__device__ __forceinline__ float dgelu_f(float x) { return dgelu_exact(x); }
+
+// Branch-free epilogue of one 32x32 accumulator tile.  Ragged rows / columns are masked by the buffer
+// range check (masked lanes get offset OOB_OFF: loads return 0, stores are dropped); all residual /
+// pre-activation loads of the tile are issued before the first use.  ACT_ID < 0: runtime p.act.
+template <bool HAS_RES, bool STORE_PRE, bool ACT, bool DACT, int ACT_ID>
+__device__ __forceinline__ void kc_epilogue_tile(const KCParams& p, const f32x16& acc, int row_base, int col,
+                                                 __amdgpu_buffer_rsrc_t rc, __amdgpu_buffer_rsrc_t rres,
+                                                 __amdgpu_buffer_rsrc_t raux) {
+    const bool col_ok = col < p.N;
+    const float bv = (p.bias && col_ok) ? (col < p.bias_split ? p.bias[col] : p.bias2[col - p.bias_split]) : 0.f;
+    unsigned offc[16];
+    float rv[16], av[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = row_base + (r & 3) + 8 * (r >> 2);
+        const bool ok = col_ok && row < p.M;
+        offc[r] = ok ? ((unsigned)row * (unsigned)p.ldc + (unsigned)col) * 4u : OOB_OFF;
+        if (HAS_RES) rv[r] = buf_load1(rres, ok ? ((unsigned)row * (unsigned)p.ldres + (unsigned)col) * 4u : OOB_OFF);
+        if (DACT) av[r] = buf_load1(raux, ok ? ((unsigned)row * (unsigned)p.ldaux + (unsigned)col) * 4u : OOB_OFF);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = row_base + (r & 3) + 8 * (r >> 2);
+        float v = acc[r] + bv;
+        if (STORE_PRE)
+            buf_store1(raux, offc[r] != OOB_OFF ? ((unsigned)row * (unsigned)p.ldaux + (unsigned)col) * 4u : OOB_OFF, v);
+        if (ACT) v = ACT_ID == ACT_GELU ? gelu_f(v) : act_fwd(p.act, v);
+        if (DACT) v *= ACT_ID == ACT_GELU ? dgelu_f(av[r]) : act_bwd(p.act, av[r]);
+        if (HAS_RES) v += rv[r];
+        buf_store1(rc, offc[r], v);
+    }
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void kc_epilogue(const KCParams& p, f32x16 (&acc)[TM][TN], int row0, int col0) {
+    const __amdgpu_buffer_rsrc_t rc = make_rsrc(p.C, p.c_bytes);
+    const __amdgpu_buffer_rsrc_t rres = make_rsrc(p.res ? p.res : p.C, p.res ? p.res_bytes : 0u);
+    const __amdgpu_buffer_rsrc_t raux = make_rsrc(p.aux ? p.aux : p.C, p.aux ? p.aux_bytes : 0u);
+    const bool has_res = p.res != nullptr;
+    const bool gelu = p.act == ACT_GELU;
+#define KC_EPI(HR, SP, AC, DA, ID)                                                                     \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) _Pragma("unroll") for (int i = 0; i < TM; ++i)      \
+        kc_epilogue_tile<HR, SP, AC, DA, ID>(p, acc[i][j], row0 + i * 32, col0 + j * 32, rc, rres, raux);
+    if (p.epi == 0) {
+        if (has_res) { KC_EPI(true, false, false, false, 0) } else { KC_EPI(false, false, false, false, 0) }
+    } else if (p.epi == (EPI_ACT | EPI_STORE_PRE) && gelu && !has_res) {
+        KC_EPI(false, true, true, false, ACT_GELU)
+    } else if (p.epi == EPI_ACT && gelu && !has_res) {          // inference: no pre-activation saved
+        KC_EPI(false, false, true, false, ACT_GELU)
+    } else if (p.epi == EPI_MUL_DACT && gelu && !has_res) {
+        KC_EPI(false, false, false, true, ACT_GELU)
+    } else {   // generic: any flag combination / activation (off the hot path)
+        const bool sp = p.epi & EPI_STORE_PRE, ac = p.epi & EPI_ACT, da = p.epi & EPI_MUL_DACT;
+        if (da) { if (has_res) { KC_EPI(true, false, false, true, -1) } else { KC_EPI(false, false, false, true, -1) } }
+        else if (sp && ac) { if (has_res) { KC_EPI(true, true, true, false, -1) } else { KC_EPI(false, true, true, false, -1) } }
+        else if (ac) { if (has_res) { KC_EPI(true, false, true, false, -1) } else { KC_EPI(false, false, true, false, -1) } }
+        else { if (has_res) { KC_EPI(true, true, false, false, -1) } else { KC_EPI(false, true, false, false, -1) } }
+    }
+#undef KC_EPI
+}
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split3(const float4 v, bf16x4& hi, bf16x4& mid, bf16x4& lo) {
+    const float xs[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const __bf16 h = (__bf16)xs[i];
+        const float r1 = xs[i] - (float)h;
+        const __bf16 m = (__bf16)r1;
+        const float r2 = r1 - (float)m;
+        hi[i] = h; mid[i] = m; lo[i] = (__bf16)r2;
+    }
+}
+
+struct MCParams {
+    const float* A; long long lda; int Mi;
+    const float* B; long long ldb; int Nj;
+    float* slab;
+    int Mk, chunks_per_split, splits;
+    int H, W, Cin;   // im2col view of B: image [B,H,W,Cin] with pixel pitch ldb, j = tap*Cin + ci
+    unsigned a_bytes, b_bytes;
+};
+struct MCPlan { int big; int splits; int chunks_per_split; size_t slab_floats; };
+struct KCTile { int bm, bn, bk; };
+
+// engine selection / tile choice (pa2d_gemm.hip)
+int gemm_mode();
+bool use_split(int N, bool im2col, int Cin);
+KCTile kc_tile(int M, int N, bool im2col, int Cin);
+// exact fp32 engine (pa2d_gemm_kc.hip): launches the tile variant `t` on a filled-in KCParams
+int launch_kc_f32(const KCParams& p, bool im2col, const KCTile& t, hipStream_t st);
+// bf16 engines (pa2d_gemm_split.hip)
+int launch_kc_split(KCParams& p, bool im2col, hipStream_t st);
+size_t planes_bytes(long long rows, int C, int NT);
+int launch_split_planes(const float* src, long long ld, void* dst, long long rows, int C, int NT, hipStream_t st);
+int launch_repack_split(const float* w0, const float* w1, void* dst, int bwd, int NT, int C, int Cin, hipStream_t st);
+// weight-gradient engine and reductions (pa2d_gemm_mc.hip)
+MCPlan plan_mc(int Mi, int Nj, int Mk);
+int launch_mc(const float* A, long long lda, int Mi, const float* B, long long ldb, int Nj, int Mk, bool im2col,
+              int H, int W, int Cin, float* slab, const MCPlan& pl, hipStream_t st);
+int launch_reduce(const float* slab, int nslab, long long count, float* out, float* out2, int mode, int C, int Cin,
+                  hipStream_t st);
+int pa2d_launch_reduce(const float* slab, int nslab, long long count, float* out, hipStream_t st);
+int colsum_blocks(int M);
+int launch_colsum(const float* X, long long ld, int M, int N, float* out, float* partial, hipStream_t st,
+                  float* out2 = nullptr, int split = 0);
