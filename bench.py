@@ -36,6 +36,7 @@ from transformerbasednavierstokesolver_amd import synth, harness, ops, ddp  # no
 from transformerbasednavierstokesolver_amd.optim import FusedAdamW  # noqa: E402
 from transformerbasednavierstokesolver_amd.utils.testloss import TestLoss, FusedTestLoss  # noqa: E402
 
+PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md, chip-level parameters
 CONV_KERNEL = "gemm_kc_kernel<128,128,2,2,true,32>"
 
@@ -218,8 +219,13 @@ def main():
                 traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roof = {"bound": "mfma", "kernel": CONV_KERNEL, "achieved": round(achieved, 2), "peak": PEAK_FP32_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": traffic,
+        # exact engine: fp32 MFMA peak.  Split engine: 6 bf16 MFMA terms per fp32 product -> fp32-equivalent peak =
+        # dense bf16 peak / 6.  bf16-compute mode: dense bf16 MFMA peak.
+        kernel, peak = {0: (CONV_KERNEL, PEAK_FP32_MFMA_TFLOPS),
+                        1: ("gemm_kc_split_kernel<128,128,true,3,true>", round(PEAK_BF16_MFMA_TFLOPS / 6, 1)),
+                        2: ("gemm_kc_split_kernel<128,128,true,1,true>", PEAK_BF16_MFMA_TFLOPS)}[args.gemm_mode]
+        roof = {"bound": "mfma", "kernel": kernel, "achieved": round(achieved, 2), "peak": peak,
+                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                 "launches_timed": len(conv_ms), "avg_launch_ms": round(avg_ms, 4),
                 "flops_per_launch": conv_flops}
 

@@ -422,3 +422,22 @@ def test_split_engine_full_ns_model_meets_fp32_tolerances():
         test_g5_full_ns_config_forward_backward()
     finally:
         lib.pa2d_set_gemm_mode(0)
+
+
+def test_graphed_rollout_refuses_a_changed_gemm_engine():
+    """The weight-pack layout belongs to the GEMM engine that was active at capture: replaying (and refreshing the
+    packs) under another engine must fail loudly instead of feeding the captured kernels a foreign layout."""
+    from transformerbasednavierstokesolver_amd import synth, harness, _lib
+    cfg = dict(synth.NS_SMALL_CONFIG, n_layers=1)
+    m = harness.build_model(cfg, synth.synth_state_dict(cfg, seed=81), DEV).eval()
+    pos, a, _ = synth.ns_batch(1, seed=82)
+    x, fx = torch.from_numpy(pos).to(DEV), torch.from_numpy(a).to(DEV)
+    gr = harness.GraphedRollout(m, x, fx)
+    lib = _lib.load()
+    lib.pa2d_set_gemm_mode(2)
+    try:
+        with pytest.raises(RuntimeError, match="GEMM engine"):
+            gr.run(fx, 1)
+    finally:
+        lib.pa2d_set_gemm_mode(0)
+    assert gr.run(fx, 2).shape[-1] == 2

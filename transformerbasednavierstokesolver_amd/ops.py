@@ -120,10 +120,14 @@ class _FrozenScope:
 
     def __init__(self):
         self.packs = {}
+        self.mode = _L().pa2d_get_gemm_mode()      # pack layout depends on the GEMM engine
 
     def refresh(self):
         """Re-pack every entry in place (same device pointers): called before replaying a hipGraph that was captured
         inside this scope, so the graph's conv launches always see the current weights."""
+        if _L().pa2d_get_gemm_mode() != self.mode:
+            raise RuntimeError("the GEMM engine (pa2d_set_gemm_mode) changed since these weight packs / this hipGraph "
+                               "were made; capture again under the new engine")
         for (_, _, B, H, W, Cc, direction), (wx, wf, pack) in self.packs.items():
             _lib.check(_L().pa2d_conv3x3x2_pack(_p(wx), _p(wf), pack.data_ptr(), pack.numel(), B, H, W, Cc, direction,
                                                 _stream()), "conv3x3x2_pack")
@@ -152,6 +156,8 @@ def _conv_pack(wx, wf, B, H, W, Cc, direction):
     if not _frozen:
         return 0
     scope = _frozen[-1]
+    if _L().pa2d_get_gemm_mode() != scope.mode:
+        raise RuntimeError("pa2d_set_gemm_mode() was called inside a weights_frozen() scope")
     key = (wx.data_ptr(), wf.data_ptr(), B, H, W, Cc, direction)
     hit = scope.packs.get(key)
     if hit is None:
