@@ -8,7 +8,9 @@
  * transformerbasednavierstokesolver_amd/_lib.py.
  *
  * Conventions
- *   - all tensors fp32, row-major, device pointers; "ld*" = row pitch in floats;
+ *   - all tensors fp32, row-major, device pointers; "ld*" = row pitch in floats; an operand may not extend
+ *     past 4 GiB (32-bit buffer descriptors): larger problems return PA2D_ERR_UNSUPPORTED before any launch;
+ *   - empty problems (batch 0) are valid: maps are no-ops, reductions are zero-filled;
  *   - the caller owns every buffer (outputs and workspaces); nothing here allocates, frees or
  *     synchronises; the only process-wide state is the engine selector pa2d_set_gemm_mode -> safe
  *     under hipGraph capture and on any stream;
@@ -35,13 +37,15 @@ enum pa2d_act { PA2D_ACT_NONE = 0, PA2D_ACT_GELU = 1, PA2D_ACT_TANH = 2, PA2D_AC
 
 const char* pa2d_version(void);
 
-/* Process-wide engine selection for the conv implicit GEMMs (also env PA2D_GEMM=f32|split at first use):
- * 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), the default and what bench.py measures;
- * 1 = experimental: operands split into 3 bf16 terms, 6 bf16 MFMA terms per product, fp32 accumulate
- *     (fp32-level accuracy, same parity tolerances);
- * 2 = bf16 compute (env PA2D_GEMM=bf16): every GEMM (conv, linears, weight gradients) rounds its
- *     operands to bf16 while staging and uses ONE bf16 MFMA term with fp32 accumulation; tensors stay
- *     fp32 in HBM.  Autocast-style numerics for BASELINE configs[2]/[4] (tolerance rel-L2 <= 3e-2). */
+/* Process-wide GEMM engine selection (also env PA2D_GEMM=f32|split|bf16 at first use):
+ * 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), the default and what bench.py reports as `value`;
+ * 1 = fp32-accurate split (conv GEMMs: forward, data and weight gradients): operands split exactly into 3 bf16
+ *     terms, 6 bf16 MFMA terms per product, fp32 accumulate — same parity tolerances as mode 0;
+ *     activations feeding a conv are pre-split once per call into the conv workspace;
+ * 2 = bf16 compute: every GEMM (conv, linears, weight gradients) rounds its operands to bf16 and uses ONE bf16
+ *     MFMA term with fp32 accumulation; tensors stay fp32 in HBM.  Autocast-style numerics for BASELINE
+ *     configs[2]/[4] (tolerance rel-L2 <= 3e-2).
+ * Workspace sizes and weight-pack layouts depend on the mode: query them, and make packs, under the mode used. */
 void pa2d_set_gemm_mode(int mode);
 int pa2d_get_gemm_mode(void);
 
