@@ -169,12 +169,21 @@ static size_t conv_planes_bytes(int M, int N, int Cin) {
     return (planes_bytes(M, Cin, gemm_mode() == 2 ? 1 : 3) + 255) & ~(size_t)255;
 }
 
-// backward workspace: [weight pack | slabs or column-sum partials | activation planes (bf16 engines)]
+// bf16 engines: the weight gradient also runs from pre-split planes (of dOut and of X) when the tile shapes allow
+static bool conv_dw_from_planes(int M, int C) {
+    return conv_planes_bytes(M, C, 2 * C) != 0 && mc_planes_supported(C, C) && plan_mc(2 * C, 9 * C, M).big;
+}
+static size_t conv_xplanes_bytes(int M, int C) {
+    return conv_dw_from_planes(M, C) ? ((planes_bytes(M, C, gemm_mode() == 2 ? 1 : 3) + 255) & ~(size_t)255) : 0;
+}
+
+// backward workspace: [weight pack | slabs or column-sum partials | dOut planes | X planes]  (planes: bf16 engines)
 size_t pa2d_conv3x3x2_workspace(int B, int H, int W, int C) {
     const size_t pack = (size_t)3 * C * 9 * C;      // fp32 pack (2C*9C floats) or 3 bf16 planes (1.5x)
     const MCPlan pl = plan_mc(2 * C, 9 * C, B * H * W);
     size_t sl = pl.slab_floats, cs = (size_t)colsum_blocks(B * H * W) * 2 * C;
-    return (pack + (sl > cs ? sl : cs)) * sizeof(float) + conv_planes_bytes(B * H * W, C, 2 * C);
+    return (pack + (sl > cs ? sl : cs)) * sizeof(float) + conv_planes_bytes(B * H * W, C, 2 * C) +
+           conv_xplanes_bytes(B * H * W, C);
 }
 
 // forward workspace: [weight pack (unused if prepacked) | activation planes (bf16 engines)]
@@ -246,18 +255,20 @@ int pa2d_conv3x3x2_bwd(const float* dout, const float* xn, const float* wx, cons
     float* scratch = (float*)ws + (size_t)3 * C * 9 * C;
     const int M = B * H * W;
     int rc;
+    const int NT = gemm_mode() == 2 ? 1 : 3;
+    const size_t apl = conv_planes_bytes(M, C, 2 * C), xpl = conv_xplanes_bytes(M, C);
+    void* const planes = (char*)ws + pa2d_conv3x3x2_workspace(B, H, W, C) - apl - xpl;     // dOut planes
+    void* const xplanes = (char*)planes + apl;                                               // X planes
+    if (apl && (dxn || xpl)) {
+        rc = launch_split_planes(dout, 2 * C, planes, M, 2 * C, NT, st);
+        if (rc) return rc;
+    }
     if (dxn) {
         const float* pack = (const float*)prepacked;
         if (!pack) {
             rc = conv_pack(wx, wf, (float*)ws, M, C, 1, st);
             if (rc) return rc;
             pack = (const float*)ws;
-        }
-        const size_t apl = conv_planes_bytes(M, C, 2 * C);
-        void* const planes = (char*)ws + pa2d_conv3x3x2_workspace(B, H, W, C) - apl;
-        if (apl) {
-            rc = launch_split_planes(dout, 2 * C, planes, M, 2 * C, gemm_mode() == 2 ? 1 : 3, st);
-            if (rc) return rc;
         }
         KCParams p = {};
         p.A = apl ? (const float*)planes : dout; p.apre = apl ? 1 : 0;
@@ -267,7 +278,13 @@ int pa2d_conv3x3x2_bwd(const float* dout, const float* xn, const float* wx, cons
         if (rc) return rc;
     }
     const MCPlan pl = plan_mc(2 * C, 9 * C, M);
-    rc = launch_mc(dout, 2 * C, 2 * C, xn, C, 9 * C, M, true, H, W, C, scratch, pl, st);
+    if (xpl) {      // bf16 engines: both operands as pre-split planes, transposed LDS reads, no conversion in the GEMM
+        rc = launch_split_planes(xn, C, xplanes, M, C, NT, st);
+        if (rc) return rc;
+        rc = launch_mc_planes(planes, xplanes, C, C, M, H, W, scratch, pl, NT, st);
+    } else {
+        rc = launch_mc(dout, 2 * C, 2 * C, xn, C, 9 * C, M, true, H, W, C, scratch, pl, st);
+    }
     if (rc) return rc;
     rc = launch_reduce(scratch, pl.splits, (long long)2 * C * 9 * C, dwx, dwf, 1, C, C, st);
     if (rc) return rc;

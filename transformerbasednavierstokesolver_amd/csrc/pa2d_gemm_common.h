@@ -133,6 +133,10 @@ int launch_mc(const float* A, long long lda, int Mi, const float* B, long long l
 int launch_reduce(const float* slab, int nslab, long long count, float* out, float* out2, int mode, int C, int Cin,
                   hipStream_t st);
 int pa2d_launch_reduce(const float* slab, int nslab, long long count, float* out, hipStream_t st);
+// weight gradient from pre-split planes (pa2d_gemm_mc_planes.hip)
+bool mc_planes_supported(int C, int Cin);
+int launch_mc_planes(const void* PA, const void* PB, int C, int Cin, int Mk, int H, int W, float* slab,
+                     const MCPlan& pl, int NT, hipStream_t st);
 int colsum_blocks(int M);
 int launch_colsum(const float* X, long long ld, int M, int N, float* out, float* partial, hipStream_t st,
                   float* out2 = nullptr, int split = 0);

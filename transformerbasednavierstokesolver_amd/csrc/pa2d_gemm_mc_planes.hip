@@ -1,0 +1,204 @@
+// Conv weight gradient on the bf16 matrix cores from PRE-SPLIT operand planes (bf16 engines, gfx950 / CDNA4):
+//     dW[i][j = tap*Cin + ci] = sum_m dOut[m][i] * X[m shifted by tap][ci]
+// Both operands are contracted over their ROW index m, so the MFMA operands (8 consecutive k = m per lane) are
+// k-strided in memory.  The planes made by split_planes_kernel ([row][32-channel chunk][plane][32] bf16) are staged
+// ROW-MAJOR into LDS with plain 16-byte copies (no conversion, half the bytes of an fp32 tile per plane) and the
+// operands are fetched with gfx950's transposed LDS read ds_read_b64_tr_b16 (per 16-lane group a 4-row x 16-column
+// block, delivered column-major: lane i gets column i, row e in element e — mapping checked on the device by
+// tools/probes/tr_read_probe.hip).  LDS image per plane: [16 rows][128 columns] bf16 = 256-byte rows with the 16-byte
+// chunk index XOR-swizzled by ((row&3)<<2 | (row>>2)&3), which keeps the transposed reads conflict-free.
+// NT = 3: six MFMA terms of the exact hi+mid+lo split (fp32 accuracy); NT = 1: bf16 compute.
+#include "pa2d_gemm_common.h"
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+struct MCPlanesParams {
+    const void* PA; int chA;      // dOut planes, chA = 2C/32 chunks per row
+    const void* PB; int chB;      // X planes, chB = Cin/32
+    float* slab;
+    int Mi, Nj, Mk, chunks_per_split, splits, H, W, Cin;
+    unsigned a_bytes, b_bytes;
+};
+
+__device__ __forceinline__ unsigned img_off(int row, int ch) {       // byte offset inside one 4 KB plane image
+    return 256u * row + 16u * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
+}
+
+template <int NT>
+__global__ __launch_bounds__(256, 2) void gemm_mc_planes_kernel(const MCPlanesParams p) {
+    constexpr int PIMG = 4096;                       // one plane image: 16 rows x 256 B
+    constexpr int STAGE = 2 * NT * PIMG;             // A planes then B planes
+    constexpr int NP = 2 * NT;                       // 16-byte pieces per thread and chunk
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_i = p.Mi / 128, tiles_j = p.Nj / 128;
+    int tj, ti, split;
+    {
+        const int tiles = tiles_i * tiles_j;
+        if ((p.splits & 7) == 0) {                   // XCD-contiguous split ranges, as in gemm_mc_kernel
+            const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, q = p.splits >> 3;
+            split = xcd * q + slot / tiles;
+            const int t = slot % tiles;
+            tj = t % tiles_j;
+            ti = t / tiles_j;
+        } else {
+            tj = blockIdx.x % tiles_j;
+            ti = (blockIdx.x / tiles_j) % tiles_i;
+            split = blockIdx.x / tiles;
+        }
+    }
+    const int wm = wave >> 1, wn = wave & 1;
+    const int total_chunks = (p.Mk + 15) / 16;
+    const int c_begin = split * p.chunks_per_split;
+    const int c_end = min(total_chunks, c_begin + p.chunks_per_split);
+
+    // the 128 columns of this tile are one tap and 4 consecutive 32-channel chunks of X
+    const int j0 = tj * 128, tap = j0 / p.Cin, cb0 = (j0 - tap * p.Cin) >> 5, ca0 = (ti * 128) >> 5;
+    const int tap_dy = tap / 3 - 1, tap_dx = tap - (tap / 3) * 3 - 1, tap_shift = tap_dy * p.W + tap_dx;
+    const int HW = p.H * p.W;
+
+    const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.PA), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.PB), 0, p.b_bytes, 0x00020000);
+
+    // staging assignment: piece id q = tid + 256*s in [0, 512*NT): operand, row, chunk, plane, 16-byte piece
+    int s_row[NP];
+    unsigned s_goff[NP], s_lds[NP];
+    bool s_isb[NP];
+#pragma unroll
+    for (int s = 0; s < NP; ++s) {
+        const int q = tid + 256 * s;
+        const int op = q / (256 * NT), r = q - op * (256 * NT);
+        const int row = r / (16 * NT), rr = r - row * (16 * NT);
+        const int c = rr / (4 * NT), pp = rr - c * (4 * NT);
+        const int plane = pp >> 2, piece = pp & 3;
+        s_row[s] = row;
+        s_isb[s] = op != 0;
+        s_goff[s] = (unsigned)((((op ? cb0 : ca0) + c) * NT + plane) * 64 + piece * 16);
+        s_lds[s] = (unsigned)((op * NT + plane) * PIMG) + img_off(row, c * 4 + piece);
+    }
+    u32x4 rg[NP];
+#define MP_LOAD(c_)                                                                                       \
+    {                                                                                                     \
+        const int m0_ = (c_) * 16;                                                                        \
+        _Pragma("unroll") for (int s = 0; s < NP; ++s) {                                                  \
+            const int m_ = m0_ + s_row[s];                                                                \
+            bool ok_ = m_ < p.Mk;                                                                         \
+            int mm_ = m_;                                                                                 \
+            if (s_isb[s]) {                                                                               \
+                const int n_ = m_ % HW;                                                                   \
+                const int y_ = n_ / p.W, x_ = n_ - y_ * p.W;                                              \
+                ok_ = ok_ && (unsigned)(y_ + tap_dy) < (unsigned)p.H && (unsigned)(x_ + tap_dx) < (unsigned)p.W; \
+                mm_ = m_ + tap_shift;                                                                     \
+            }                                                                                             \
+            const unsigned rowb_ = (unsigned)mm_ * (unsigned)((s_isb[s] ? p.chB : p.chA) * NT * 64);      \
+            rg[s] = s_isb[s] ? __builtin_amdgcn_raw_buffer_load_b128(rb_rsrc, ok_ ? rowb_ + s_goff[s] : OOB_OFF, 0, 0) \
+                             : __builtin_amdgcn_raw_buffer_load_b128(ra_rsrc, ok_ ? rowb_ + s_goff[s] : OOB_OFF, 0, 0); \
+        }                                                                                                 \
+    }
+#define MP_STORE(buf_)                                                                                    \
+    {                                                                                                     \
+        _Pragma("unroll") for (int s = 0; s < NP; ++s)                                                    \
+            *reinterpret_cast<u32x4*>(smem + (buf_) * STAGE + s_lds[s]) = rg[s];                          \
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // transposed-read addresses of this lane: group g = lane>>4 covers columns 16*(g&1).. of a 32-wide tile and
+    // rows 8*(g>>1)..; lane 4q+pq of the group supplies row q, columns 4pq..4pq+3 (8 bytes)
+    const int g = lane >> 4, q4 = (lane & 15) >> 2, pq = lane & 3;
+    unsigned fa[2][2], fb[2][2];                      // [tile][read r]: byte offset inside a plane image
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 2; ++r) {
+            const int row = 8 * (g >> 1) + 4 * r + q4;
+            const int cha = ((wm * 64 + t * 32) >> 3) + 2 * (g & 1) + (pq >> 1);
+            const int chb = ((wn * 64 + t * 32) >> 3) + 2 * (g & 1) + (pq >> 1);
+            fa[t][r] = img_off(row, cha) + 8u * (pq & 1);
+            fb[t][r] = img_off(row, chb) + 8u * (pq & 1);
+        }
+
+    if (c_begin < c_end) {
+        MP_LOAD(c_begin)
+        MP_STORE(0)
+    }
+    __syncthreads();
+    for (int c = c_begin; c < c_end; ++c) {
+        const int buf = (c - c_begin) & 1;
+        if (c + 1 < c_end) MP_LOAD(c + 1)
+        const unsigned char* st = smem + buf * STAGE;
+        bf16x8 af[2][NT], bf[2][NT];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int pl = 0; pl < NT; ++pl) {
+                typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+                const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + pl * PIMG + fa[t][0]));
+                const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + pl * PIMG + fa[t][1]));
+                const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + (NT + pl) * PIMG + fb[t][0]));
+                const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + (NT + pl) * PIMG + fb[t][1]));
+                const s16x8 av = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                const s16x8 bv = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                af[t][pl] = __builtin_bit_cast(bf16x8, av);
+                bf[t][pl] = __builtin_bit_cast(bf16x8, bv);
+            }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if constexpr (NT == 3) {   // smallest terms first
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                }
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+            }
+        if (c + 1 < c_end) MP_STORE(buf ^ 1)
+        __syncthreads();
+    }
+#undef MP_LOAD
+#undef MP_STORE
+
+    float* out = p.slab + (size_t)split * p.Mi * p.Nj;
+    const int col0 = tj * 128 + wn * 64 + (lane & 31);
+    const int row0 = ti * 128 + wm * 64 + 4 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                out[(size_t)row * p.Nj + col0 + j * 32] = acc[i][j][r];
+            }
+}
+
+bool mc_planes_supported(int C, int Cin) { return (C % 64) == 0 && (Cin % 128) == 0; }
+
+// PA: planes of dOut [Mk][2C], PB: planes of X [Mk][Cin] (both NT planes per 32-channel chunk); slab as launch_mc
+int launch_mc_planes(const void* PA, const void* PB, int C, int Cin, int Mk, int H, int W, float* slab,
+                     const MCPlan& pl, int NT, hipStream_t st) {
+    if (!mc_planes_supported(C, Cin) || !pl.big) return PA2D_ERR_UNSUPPORTED;
+    MCPlanesParams p;
+    p.PA = PA; p.chA = 2 * C / 32; p.PB = PB; p.chB = Cin / 32; p.slab = slab;
+    p.Mi = 2 * C; p.Nj = 9 * Cin; p.Mk = Mk; p.chunks_per_split = pl.chunks_per_split; p.splits = pl.splits;
+    p.H = H; p.W = W; p.Cin = Cin;
+    const unsigned long long ab = (unsigned long long)Mk * p.chA * NT * 64, bb = (unsigned long long)Mk * p.chB * NT * 64;
+    if (ab >= 0xFFFFFFF0ull || bb >= 0xFFFFFFF0ull) return PA2D_ERR_UNSUPPORTED;
+    p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
+    const dim3 grid((p.Mi / 128) * (p.Nj / 128) * pl.splits);
+    if (NT == 3) hipLaunchKernelGGL((gemm_mc_planes_kernel<3>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_mc_planes_kernel<1>), grid, dim3(256), 0, st, p);
+    PA2D_CHECK_LAUNCH();
+    return PA2D_OK;
+}
