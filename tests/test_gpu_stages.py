@@ -193,7 +193,9 @@ def test_conv_split_bf16_engine_meets_fp32_tolerances(dev):
     lib.pa2d_set_gemm_mode(1)
     try:
         assert lib.pa2d_get_gemm_mode() == 1
-        for args in ((2, 6, 5, 32), (2, 64, 64, 256), (1, 21, 17, 128)):
+        # C = 256 / 128: pre-split planes + transposed-read weight gradient; C = 64 / 192: planes for the data GEMMs,
+        # register-split gather fallback for the weight gradient; C = 32: small tiles stay on the exact engine
+        for args in ((2, 6, 5, 32), (2, 64, 64, 256), (1, 21, 17, 128), (2, 16, 16, 64), (1, 12, 20, 192)):
             test_conv3x3x2(dev, *args)
     finally:
         lib.pa2d_set_gemm_mode(0)
@@ -215,6 +217,8 @@ def test_bf16_compute_mode_stage_tolerances(dev, monkeypatch):
         assert lib.pa2d_get_gemm_mode() == 2
         test_conv3x3x2(dev, 2, 64, 64, 256)
         test_conv3x3x2(dev, 1, 21, 17, 128)
+        test_conv3x3x2(dev, 2, 16, 16, 64)
+        test_conv3x3x2(dev, 1, 12, 20, 192)
         test_linear(dev, 4096, 256, 256, "gelu")
         test_linear(dev, 1000, 512, 76, None)
     finally:
