@@ -53,6 +53,7 @@ static int launch_kc(const KCParams& p_in, bool im2col, hipStream_t st, hipEvent
     }
     if ((p.K & 3) || (p.lda & 3) || (p.ldb & 3)) return PA2D_ERR_ARG;
     if (im2col && ((p.Cin & 15) || p.K != 9 * p.Cin)) return PA2D_ERR_UNSUPPORTED;
+    if (im2col && (p.epi != 0 || p.res)) return PA2D_ERR_ARG;      // conv kernels carry the bias-only epilogue
     if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return PA2D_ERR_ARG;
     int rc;
     if (use_split(p.N, im2col, p.Cin)) rc = launch_kc_split(p, im2col, st);

@@ -61,7 +61,8 @@ __device__ __forceinline__ void kc_epilogue_tile(const KCParams& p, const f32x16
     }
 }
 
-template <int TM, int TN>
+// BIAS_ONLY: the conv implicit GEMMs only ever store acc (+ bias): one variant instead of nine (compile time)
+template <int TM, int TN, bool BIAS_ONLY = false>
 __device__ __forceinline__ void kc_epilogue(const KCParams& p, f32x16 (&acc)[TM][TN], int row0, int col0) {
     const __amdgpu_buffer_rsrc_t rc = make_rsrc(p.C, p.c_bytes);
     const __amdgpu_buffer_rsrc_t rres = make_rsrc(p.res ? p.res : p.C, p.res ? p.res_bytes : 0u);
@@ -71,7 +72,9 @@ __device__ __forceinline__ void kc_epilogue(const KCParams& p, f32x16 (&acc)[TM]
 #define KC_EPI(HR, SP, AC, DA, ID)                                                                     \
     _Pragma("unroll") for (int j = 0; j < TN; ++j) _Pragma("unroll") for (int i = 0; i < TM; ++i)      \
         kc_epilogue_tile<HR, SP, AC, DA, ID>(p, acc[i][j], row0 + i * 32, col0 + j * 32, rc, rres, raux);
-    if (p.epi == 0) {
+    if constexpr (BIAS_ONLY) {
+        KC_EPI(false, false, false, false, 0)
+    } else if (p.epi == 0) {
         if (has_res) { KC_EPI(true, false, false, false, 0) } else { KC_EPI(false, false, false, false, 0) }
     } else if (p.epi == (EPI_ACT | EPI_STORE_PRE) && gelu && !has_res) {
         KC_EPI(false, true, true, false, ACT_GELU)

@@ -125,6 +125,6 @@ __global__ __launch_bounds__(256, 2) void gemm_kc_kernel(const KCParams p) {
 #undef KC_STORE
 
     // epilogue: lanes 0-31 of register r write 32 consecutive floats of one row (128 B)
-    kc_epilogue<TM, TN>(p, acc, tile_m * BM + wm * WM + 4 * (lane >> 5), tile_n * BN + wn * WN + (lane & 31));
+    kc_epilogue<TM, TN, IM2COL>(p, acc, tile_m * BM + wm * WM + 4 * (lane >> 5), tile_n * BN + wn * WN + (lane & 31));
 }
 

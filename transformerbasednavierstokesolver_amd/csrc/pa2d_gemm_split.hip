@@ -240,7 +240,7 @@ __global__ __launch_bounds__(512, 2) void gemm_kc_split_kernel(const KCParams p)
         __syncthreads();
     }
 
-    kc_epilogue<TM, TN>(p, acc, tile_m * BM + wm * WM + 4 * (lane >> 5), tile_n * BN + wn * WN + (lane & 31));
+    kc_epilogue<TM, TN, IM2COL>(p, acc, tile_m * BM + wm * WM + 4 * (lane >> 5), tile_n * BN + wn * WN + (lane & 31));
 }
 
 // Variants in use: conv (im2col) GEMMs always take pre-split activation planes (NT = 3: fp32-accurate split,
