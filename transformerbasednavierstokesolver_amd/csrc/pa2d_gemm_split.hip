@@ -26,7 +26,7 @@
 // split_planes_kernel), so BOTH tiles are staged with 16-byte copies and the producers do no conversion work:
 // each activation element is converted once instead of once per (tap, column tile) = 36 times.
 template <int BM, int BN, bool IM2COL, int NT, bool APRE = false>
-__global__ __launch_bounds__(512, 2) void gemm_kc_split_kernel(const KCParams p) {
+__global__ __launch_bounds__(512, (BM + BN > 256) ? 1 : 2) void gemm_kc_split_kernel(const KCParams p) {
     constexpr int BK = 32, PITCHB = NT * 64 + 16;        // bytes per LDS row (NT planes x 64 B + 16): 208 / 80
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int A_IT = BM / 32, B_IT = BN / 32;        // float4 per producer thread per K-step
@@ -267,6 +267,21 @@ int launch_kc_split(KCParams& p, bool im2col, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_done = true;
     }
+    static int big = -1;
+    if (big < 0) { const char* e = getenv("PA2D_SPLIT_BIG"); big = e ? atoi(e) : 1; }
+    if (big && im2col && !bf && (p.M % 256) == 0 && (long long)(p.M / 256) * tiles_n >= 512) {
+        // 256x128 workgroup tile (128x64 per consumer wave): 25 % less L2->LDS staging and LDS reads per MFMA
+        const int smem_big = 2 * (256 + 128) * 208;
+        static bool attr_big = false;
+        if (!attr_big) {
+            hipError_t eb = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kc_split_kernel<256, 128, true, 3, true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, smem_big);
+            if (eb != hipSuccess) return (int)eb;
+            attr_big = true;
+        }
+        const dim3 gbig(ceil_div(p.M / 256, 8) * 8 * tiles_n);
+        hipLaunchKernelGGL((gemm_kc_split_kernel<256, 128, true, 3, true>), gbig, dim3(512), smem_big, st, p);
+    } else
     if (!im2col) hipLaunchKernelGGL((gemm_kc_split_kernel<128, 128, false, 1, false>), grid, dim3(512), smem, st, p);
     else if (bf) hipLaunchKernelGGL((gemm_kc_split_kernel<128, 128, true, 1, true>), grid, dim3(512), smem, st, p);
     else hipLaunchKernelGGL((gemm_kc_split_kernel<128, 128, true, 3, true>), grid, dim3(512), smem, st, p);
