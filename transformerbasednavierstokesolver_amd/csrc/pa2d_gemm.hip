@@ -15,7 +15,12 @@ int gemm_mode() {
 // (the split engine serves the conv implicit GEMMs only: the short-K linears gain nothing from it)
 // K-step: 32 (half the barriers of 16, full 128-byte row segments; 3-4 % faster on the conv, ~10 % on the small tiles)
 // whenever the layout allows it: plain GEMMs always, the conv when Cin % 32 == 0; otherwise 16.
-static int kc_bk(bool im2col, int Cin) { return (!im2col || (Cin % 32) == 0) ? 32 : 16; }
+static int kc_bk(bool im2col, int Cin) {
+    static int force16 = -1;      // PA2D_KC_BK=16: 16-wide K-step for the conv (124 VGPRs, 40 KB LDS -> 4 workgroups per CU)
+    if (force16 < 0) { const char* e = getenv("PA2D_KC_BK"); force16 = (e && atoi(e) == 16) ? 1 : 0; }
+    if (im2col && force16) return 16;
+    return (!im2col || (Cin % 32) == 0) ? 32 : 16;
+}
 // tile choice of the fp32 engine: 128x128 when that already gives >= 1.5 workgroups per CU, otherwise smaller
 // tiles so that small problems (rollout at batch 1: M = 4096) still fill the 256 CUs.  Shared by the launch and
 // by the conv weight packs (the pack's channel chunk must equal the K-step).
