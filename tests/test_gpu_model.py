@@ -249,13 +249,14 @@ def test_bf16_compute_mode_full_ns_model():
     pos, a, u = synth.ns_batch(1, seed=52)
     x, fx = torch.from_numpy(pos).to(DEV), torch.from_numpy(a).to(DEV)
     lib = _lib.load()
+    prev_mode = lib.pa2d_get_gemm_mode()
     lib.pa2d_set_gemm_mode(2)
     try:
         pred = m(x, fx=fx)
         pred.square().sum().backward()
         e = rel_l2(pred.reshape(-1), g["pred"])
     finally:
-        lib.pa2d_set_gemm_mode(0)
+        lib.pa2d_set_gemm_mode(prev_mode)
     assert 1e-5 < e < 3e-2, e          # really ran in reduced precision, and within the bf16 tolerance
     assert all(torch.isfinite(p.grad).all() for k, p in m.named_parameters() if p.grad is not None)
 
@@ -417,11 +418,12 @@ def test_split_engine_full_ns_model_meets_fp32_tolerances():
     the SAME fp32 tolerances as the exact engine."""
     from transformerbasednavierstokesolver_amd import _lib
     lib = _lib.load()
+    prev_mode = lib.pa2d_get_gemm_mode()
     lib.pa2d_set_gemm_mode(1)
     try:
         test_g5_full_ns_config_forward_backward()
     finally:
-        lib.pa2d_set_gemm_mode(0)
+        lib.pa2d_set_gemm_mode(prev_mode)
 
 
 def test_graphed_rollout_refuses_a_changed_gemm_engine():
@@ -434,10 +436,11 @@ def test_graphed_rollout_refuses_a_changed_gemm_engine():
     x, fx = torch.from_numpy(pos).to(DEV), torch.from_numpy(a).to(DEV)
     gr = harness.GraphedRollout(m, x, fx)
     lib = _lib.load()
+    prev_mode = lib.pa2d_get_gemm_mode()
     lib.pa2d_set_gemm_mode(2)
     try:
         with pytest.raises(RuntimeError, match="GEMM engine"):
             gr.run(fx, 1)
     finally:
-        lib.pa2d_set_gemm_mode(0)
+        lib.pa2d_set_gemm_mode(prev_mode)
     assert gr.run(fx, 2).shape[-1] == 2

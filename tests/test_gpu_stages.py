@@ -190,6 +190,7 @@ def test_conv_split_bf16_engine_meets_fp32_tolerances(dev):
     accumulate — must meet the SAME fp32 tolerances as the exact fp32 MFMA engine."""
     from transformerbasednavierstokesolver_amd import _lib
     lib = _lib.load()
+    prev_mode = lib.pa2d_get_gemm_mode()
     lib.pa2d_set_gemm_mode(1)
     try:
         assert lib.pa2d_get_gemm_mode() == 1
@@ -198,8 +199,8 @@ def test_conv_split_bf16_engine_meets_fp32_tolerances(dev):
         for args in ((2, 6, 5, 32), (2, 64, 64, 256), (1, 21, 17, 128), (2, 16, 16, 64), (1, 12, 20, 192)):
             test_conv3x3x2(dev, *args)
     finally:
-        lib.pa2d_set_gemm_mode(0)
-    assert lib.pa2d_get_gemm_mode() == 0
+        lib.pa2d_set_gemm_mode(prev_mode)
+    assert lib.pa2d_get_gemm_mode() == prev_mode
 
 
 def test_bf16_compute_mode_stage_tolerances(dev, monkeypatch):
@@ -212,6 +213,7 @@ def test_bf16_compute_mode_stage_tolerances(dev, monkeypatch):
     lib = _lib.load()
     monkeypatch.setattr(mod, "FWD_TOL", 1e-2)
     monkeypatch.setattr(mod, "BWD_TOL", 1e-2)
+    prev_mode = lib.pa2d_get_gemm_mode()
     lib.pa2d_set_gemm_mode(2)
     try:
         assert lib.pa2d_get_gemm_mode() == 2
@@ -222,4 +224,4 @@ def test_bf16_compute_mode_stage_tolerances(dev, monkeypatch):
         test_linear(dev, 4096, 256, 256, "gelu")
         test_linear(dev, 1000, 512, 76, None)
     finally:
-        lib.pa2d_set_gemm_mode(0)
+        lib.pa2d_set_gemm_mode(prev_mode)
