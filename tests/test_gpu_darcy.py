@@ -50,8 +50,7 @@ def _pos(H, W, ref, dtype):
     return _POS_CACHE[key].to(DEV).to(dtype)
 
 
-def test_darcy_421_attention_forward_backward(oracle_on_gpu):
-    orc = oracle_on_gpu
+def _darcy_attention(orc, fwd_tol, dx_tol, grad_tol, qk_tol):
     from transformerbasednavierstokesolver_amd import synth
     from transformerbasednavierstokesolver_amd.model.Physics_Attention import Physics_Attention_Structured_Mesh_2D
     H = W = 421
@@ -72,11 +71,29 @@ def test_darcy_421_attention_forward_backward(oracle_on_gpu):
     xo = x.detach().double().requires_grad_(True)
     yo = orc.physics_attention(xo, sdo, pre, H, W, h)
     yo.backward(gy.double())
-    assert rel_l2(y, yo) < 5e-6
-    assert rel_l2(x.grad, xo.grad) < 5e-5
+    assert rel_l2(y, yo) < fwd_tol
+    assert rel_l2(x.grad, xo.grad) < dx_tol
     for k, p in a.named_parameters():
-        tol = 2e-3 if ("to_q" in k or "to_k" in k) else 1e-4
+        tol = qk_tol if ("to_q" in k or "to_k" in k) else grad_tol
         assert rel_l2(p.grad, sdo[pre + k].grad) < tol, k
+
+
+def test_darcy_421_attention_forward_backward(oracle_on_gpu):
+    _darcy_attention(oracle_on_gpu, fwd_tol=5e-6, dx_tol=5e-5, grad_tol=1e-4, qk_tol=2e-3)
+
+
+def test_darcy_421_attention_bf16_compute_mode(oracle_on_gpu):
+    """BASELINE configs[4] in its stated numerics: Darcy 421 x 421 (N = 177 241, a multiple of no tile size),
+    C = 128, M = 128 through the bf16-compute engine (pre-converted planes, transposed-read weight gradient).
+    SURVEY 8c: bf16 forward tolerance 3e-2 (the reference under bf16 autocast is 1.4-1.6e-2 from fp64)."""
+    from transformerbasednavierstokesolver_amd import _lib
+    lib = _lib.load()
+    prev_mode = lib.pa2d_get_gemm_mode()
+    lib.pa2d_set_gemm_mode(2)
+    try:
+        _darcy_attention(oracle_on_gpu, fwd_tol=3e-2, dx_tol=5e-2, grad_tol=5e-2, qk_tol=0.5)
+    finally:
+        lib.pa2d_set_gemm_mode(prev_mode)
 
 
 def test_darcy_421_model_training_step(oracle_on_gpu):
