@@ -25,11 +25,13 @@ __device__ __forceinline__ unsigned img_off(int row, int ch) {       // byte off
     return 256u * row + 16u * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3)));
 }
 
-template <int NT>
+// KS = 16-row K-steps per LDS stage (one barrier per stage): 1 for NT = 3 (24 MFMAs per wave and barrier, 48 KB of LDS),
+// 4 for NT = 1 (16 MFMAs per barrier instead of 4, 64 KB).
+template <int NT, int KS>
 __global__ __launch_bounds__(256, 2) void gemm_mc_planes_kernel(const MCPlanesParams p) {
-    constexpr int PIMG = 4096;                       // one plane image: 16 rows x 256 B
-    constexpr int STAGE = 2 * NT * PIMG;             // A planes then B planes
-    constexpr int NP = 2 * NT;                       // 16-byte pieces per thread and chunk
+    constexpr int PIMG = 4096;                       // one plane image of one K-step: 16 rows x 256 B
+    constexpr int STAGE = 2 * NT * KS * PIMG;        // A planes then B planes, KS sub-images each
+    constexpr int NP = 2 * NT * KS;                  // 16-byte pieces per thread and stage
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -69,14 +71,14 @@ __global__ __launch_bounds__(256, 2) void gemm_mc_planes_kernel(const MCPlanesPa
 #pragma unroll
     for (int s = 0; s < NP; ++s) {
         const int q = tid + 256 * s;
-        const int op = q / (256 * NT), r = q - op * (256 * NT);
-        const int row = r / (16 * NT), rr = r - row * (16 * NT);
+        const int op = q / (256 * NT * KS), r = q - op * (256 * NT * KS);
+        const int row = r / (16 * NT), rr = r - row * (16 * NT);          // row in [0, 16*KS)
         const int c = rr / (4 * NT), pp = rr - c * (4 * NT);
         const int plane = pp >> 2, piece = pp & 3;
         s_row[s] = row;
         s_isb[s] = op != 0;
         s_goff[s] = (unsigned)((((op ? cb0 : ca0) + c) * NT + plane) * 64 + piece * 16);
-        s_lds[s] = (unsigned)((op * NT + plane) * PIMG) + img_off(row, c * 4 + piece);
+        s_lds[s] = (unsigned)(((op * NT + plane) * KS + (row >> 4)) * PIMG) + img_off(row & 15, c * 4 + piece);
     }
     u32x4 rg[NP];
 #define MP_LOAD(c_)                                                                                       \
@@ -84,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mc_planes_kernel(const MCPlanesPa
         const int m0_ = (c_) * 16;                                                                        \
         _Pragma("unroll") for (int s = 0; s < NP; ++s) {                                                  \
             const int m_ = m0_ + s_row[s];                                                                \
-            bool ok_ = m_ < p.Mk;                                                                         \
+            bool ok_ = m_ < p.Mk && (KS == 1 || (c_) + (s_row[s] >> 4) < c_end);   /* next split's rows stay out */ \
             int mm_ = m_;                                                                                 \
             if (s_isb[s]) {                                                                               \
                 const int n_ = m_ % HW;                                                                   \
@@ -131,20 +133,22 @@ __global__ __launch_bounds__(256, 2) void gemm_mc_planes_kernel(const MCPlanesPa
         MP_STORE(0)
     }
     __syncthreads();
-    for (int c = c_begin; c < c_end; ++c) {
-        const int buf = (c - c_begin) & 1;
-        if (c + 1 < c_end) MP_LOAD(c + 1)
-        const unsigned char* st = smem + buf * STAGE;
+    for (int c = c_begin; c < c_end; c += KS) {
+        const int buf = ((c - c_begin) / KS) & 1;
+        if (c + KS < c_end) MP_LOAD(c + KS)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+        const unsigned char* st = smem + buf * STAGE + ks * PIMG;
         bf16x8 af[2][NT], bf[2][NT];
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int pl = 0; pl < NT; ++pl) {
                 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-                const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + pl * PIMG + fa[t][0]));
-                const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + pl * PIMG + fa[t][1]));
-                const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + (NT + pl) * PIMG + fb[t][0]));
-                const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + (NT + pl) * PIMG + fb[t][1]));
+                const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + pl * KS * PIMG + fa[t][0]));
+                const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + pl * KS * PIMG + fa[t][1]));
+                const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + (NT + pl) * KS * PIMG + fb[t][0]));
+                const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + (NT + pl) * KS * PIMG + fb[t][1]));
                 const s16x8 av = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
                 const s16x8 bv = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
                 af[t][pl] = __builtin_bit_cast(bf16x8, av);
@@ -163,7 +167,8 @@ __global__ __launch_bounds__(256, 2) void gemm_mc_planes_kernel(const MCPlanesPa
                 }
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
             }
-        if (c + 1 < c_end) MP_STORE(buf ^ 1)
+        }
+        if (c + KS < c_end) MP_STORE(buf ^ 1)
         __syncthreads();
     }
 #undef MP_LOAD
@@ -197,8 +202,8 @@ int launch_mc_planes(const void* PA, const void* PB, int C, int Cin, int Mk, int
     if (ab >= 0xFFFFFFF0ull || bb >= 0xFFFFFFF0ull) return PA2D_ERR_UNSUPPORTED;
     p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
     const dim3 grid((p.Mi / 128) * (p.Nj / 128) * pl.splits);
-    if (NT == 3) hipLaunchKernelGGL((gemm_mc_planes_kernel<3>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((gemm_mc_planes_kernel<1>), grid, dim3(256), 0, st, p);
+    if (NT == 3) hipLaunchKernelGGL((gemm_mc_planes_kernel<3, 1>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_mc_planes_kernel<1, 4>), grid, dim3(256), 0, st, p);
     PA2D_CHECK_LAUNCH();
     return PA2D_OK;
 }
