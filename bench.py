@@ -102,6 +102,22 @@ def cpu_baseline(cfg, sd, pos, a, u, threads):
     return dt, pred, float(loss)
 
 
+CPU_ROLLOUT_STEPS = 4
+
+
+def cpu_rollout_baseline(cfg, sd, pos, a, threads):
+    """Oracle prediction-feedback loop (ns_vorticity_unrolling.py:264-286) on the CPU: one trajectory,
+    CPU_ROLLOUT_STEPS steps, no grad.  Returns steps/s."""
+    from oracle import transolver_oracle as orc
+    torch.set_num_threads(threads)
+    sdo = orc.to_torch(sd, torch.float32)
+    x, fx = (torch.from_numpy(np.ascontiguousarray(t[:1])) for t in (pos, a))
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        orc.rollout(sdo, x, fx, cfg, CPU_ROLLOUT_STEPS)
+        return CPU_ROLLOUT_STEPS / (time.perf_counter() - t0)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -340,6 +356,11 @@ def main():
                                          f"calls of one exp_ns iteration, forward+backward, fp32 torch CPU, "
                                          f"{threads} threads: {cdt:.1f} s measured -> {it_s:.2f} s per trajectory"}
         out["rel_l2_gpu_vs_cpu_oracle"] = rel
+        if not args.no_rollout:
+            rs = cpu_rollout_baseline(cfg, sd, pos, a, threads)
+            out["cpu_baseline"]["rollout_steps_per_s_b1"] = round(rs, 3)
+            out["cpu_baseline"]["rollout_sample"] = f"{CPU_ROLLOUT_STEPS} autoregressive steps of one trajectory, no grad"
+            log(f"CPU oracle rollout: {rs:.2f} steps/s at B=1")
     pool.close()
     if rank == 0:
         print(json.dumps(out), flush=True)
