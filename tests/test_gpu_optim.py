@@ -207,6 +207,14 @@ def test_time_folding_splits_into_groups_under_the_descriptor_limit(monkeypatch)
     m = harness.build_model(cfg, sd, DEV).train()
     assert harness._fold_group(m, 2, 4096, 10) == 10
     assert harness._fold_group(harness.build_model(synth.NS_CONFIG, None, "cpu"), 64, 4096, 10) == 7   # B=64, C=256
+    from transformerbasednavierstokesolver_amd import _lib
+    lib = _lib.load()
+    prev_mode = lib.pa2d_get_gemm_mode()
+    lib.pa2d_set_gemm_mode(1)                # 3-plane bf16 image of the 2C-wide gradient: 6 B per element
+    try:
+        assert harness._fold_group(harness.build_model(synth.NS_CONFIG, None, "cpu"), 64, 4096, 10) == 5
+    finally:
+        lib.pa2d_set_gemm_mode(prev_mode)
     monkeypatch.setattr(harness, "FOLD_MAX_BYTES", 4 * 2 * 64 * (4 * 2 * 4096) + 100)
     assert harness._fold_group(m, 2, 4096, 10) == 4
     calls = []

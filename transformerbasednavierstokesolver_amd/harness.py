@@ -74,7 +74,10 @@ def _fold_group(model, bsz, npoints, ncalls):
     C = inner.n_hidden
     r = max((blk.mlp.linear_pre[0].weight.shape[0] for blk in inner.blocks), default=C) / C
     width = int(max(2, r) * C)
-    rows = FOLD_MAX_BYTES // (4 * width)
+    row_bytes = 4 * width
+    if ops._L().pa2d_get_gemm_mode() == 1:      # split engine: the 2C-wide conv gradient travels as 3 bf16 planes
+        row_bytes = max(row_bytes, 6 * 2 * C)
+    rows = FOLD_MAX_BYTES // row_bytes
     return max(1, min(ncalls, rows // max(1, bsz * npoints)))
 
 
