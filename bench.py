@@ -5,16 +5,22 @@ Workload at every N (BASELINE.json configs[1], weak scaling): the exp_ns.py trai
 64x64 Navier-Stokes — 10 teacher-forced `model()` calls, summed rel-L2 loss, one backward through
 all 10 graphs, AdamW(wd=1e-5) + OneCycleLR step — for Transolver_Structured_Mesh_2D with 8 layers,
 C=256, 8 heads, M=64 slices, fp32, batch 32 trajectories PER GPU, synthetic seeded fields, inputs
-resident in HBM.  N>1 (launched by torch.distributed.run): batch sharded across ranks, one RCCL
-all-reduce(SUM) of the flat gradient bucket per iteration.
+resident in HBM.  N>1: batch sharded across ranks (one process per GPU), one RCCL all-reduce(SUM) of
+the flat gradient bucket per iteration.  `python bench.py --gpus N` starts its own N ranks (the parent
+never touches the GPU); under `python -m torch.distributed.run` it uses the ranks it was given.
 
-  value     = trajectories/s = N * 32 * K / (max over ranks of the time of K iterations)
-  roofline  = the dominant kernel, the implicit-GEMM 3x3 conv `gemm_kc_kernel<128,128,2,2,true,32>`
-              (forward and data-gradient launches have identical FLOPs): algorithmic FLOPs per launch
-              2*(B*N)*(9C)*(2C) / average launch duration measured with HIP events recorded on the
-              launch stream inside the timed region; peak = 157.3 TFLOP/s (fp32 MFMA, MI355X).
-  cpu_baseline = the CPU oracle (port of the reference, pinned to it by oracle/make_golden.py) timed on
-              this host on ONE trajectory of the same workload (rank 0, N=1 only).
+  value        = trajectories/s = N * 32 * K / (max over ranks of the time of K iterations), on the default
+                 GEMM engine (fp32-accurate 3xbf16 split for the conv GEMMs, exact fp32 MFMA elsewhere; the engine
+                 the `-m gpu` parity suite runs); the exact-fp32-MFMA engine is measured beside it
+                 (`fp32_exact_engine`)
+  roofline     = the dominant kernel (implicit-GEMM 3x3 conv, forward and data-gradient launches have identical
+                 FLOPs): algorithmic FLOPs per launch 2*(B*N)*(9C)*(2C) / average launch duration measured with
+                 HIP events recorded on the launch stream inside the timed region
+  roofline_hbm = the slice / de-slice kernels north_star names, same method, against the 8 TB/s HBM peak
+  darcy421     = BASELINE configs[4] geometry (421x421, 8 layers, C=128, M=128): exp_darcy.py iteration, with
+                 its own two rooflines
+  cpu_baseline = the CPU oracle (port of the reference, pinned to it by oracle/make_golden.py) on this host by
+                 the BASELINE.md §3 protocol (rank 0, N=1 only)
 """
 from __future__ import annotations
 
@@ -35,46 +41,67 @@ sys.path.insert(0, ROOT)
 from transformerbasednavierstokesolver_amd import synth, harness, ops, ddp  # noqa: E402
 from transformerbasednavierstokesolver_amd.optim import FusedAdamW  # noqa: E402
 from transformerbasednavierstokesolver_amd.utils.testloss import TestLoss, FusedTestLoss  # noqa: E402
+from transformerbasednavierstokesolver_amd.utils.normalizer import UnitTransformer  # noqa: E402
 
-PEAK_BF16_MFMA_TFLOPS = 2500.0   # dense bf16 MFMA, MI355X_MICROARCH.md
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # dense bf16 MFMA, MI355X_MICROARCH.md
 PEAK_FP32_MFMA_TFLOPS = 157.3     # MI355X_MICROARCH.md, chip-level parameters
-CONV_KERNEL = "gemm_kc_kernel<128,128,2,2,true,32>"
+PEAK_HBM_GBS = 8000.0             # HBM3E, MI355X_MICROARCH.md
+# dominant (conv implicit-GEMM) kernel and the MFMA peak it is priced against, per engine.  Split engine: six bf16
+# MFMA terms per fp32 product -> fp32-equivalent peak = dense bf16 peak / 6.
+CONV_KERNELS = {ops.ENGINE_F32: ("gemm_kc_kernel<128,128,2,2,true,32>", PEAK_FP32_MFMA_TFLOPS),
+                ops.ENGINE_SPLIT: ("gemm_kc_split_kernel<256,128,true,3,true>", round(PEAK_BF16_MFMA_TFLOPS / 6, 1)),
+                ops.ENGINE_BF16: ("gemm_kc_split_kernel<128,128,true,1,true>", PEAK_BF16_MFMA_TFLOPS)}
+ENGINE_LABEL = {ops.ENGINE_F32: "exact fp32 MFMA (all GEMMs)",
+                ops.ENGINE_SPLIT: "3xbf16-split/fp32-acc (conv), exact fp32 MFMA (linears)",
+                ops.ENGINE_BF16: "bf16 MFMA compute, f32 accumulate+storage (all GEMMs)"}
+# algorithmic HBM bytes per launch of the slice-path kernels, in units of R*C*4 bytes (R = B*N rows):
+# scatter reads x_mid + v; de-slice reads x_mid, writes y; slice backward reads x_mid, fx_mid, dY, writes dX, dF
+HBM_KERNELS = {"slice_scatter": ("slice_scatter_kernel", 2.0), "deslice": ("deslice_kernel", 2.0),
+               "slice_bwd": ("slice_bwd_kernel", 5.0)}
 
 
 class HipEventPool:
-    """Raw hipEvent_t pairs (libamdhip64 via ctypes) handed to libpa2d, which records them on the
-    launch stream right around the conv implicit-GEMM kernel."""
+    """Raw hipEvent_t pairs (libamdhip64 via ctypes) handed to libpa2d, which records them on the launch stream
+    right around one kernel.  `provider(kind)` is installed as ops.event_provider."""
 
-    def __init__(self, npairs):
+    def __init__(self):
         self.hip = ctypes.CDLL("libamdhip64.so")
         self.hip.hipEventCreate.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
         self.hip.hipEventElapsedTime.argtypes = [ctypes.POINTER(ctypes.c_float), ctypes.c_void_p, ctypes.c_void_p]
         self.hip.hipEventDestroy.argtypes = [ctypes.c_void_p]
-        self.pairs = []
-        for _ in range(npairs):
-            a, b = ctypes.c_void_p(), ctypes.c_void_p()
-            assert self.hip.hipEventCreate(ctypes.byref(a)) == 0 and self.hip.hipEventCreate(ctypes.byref(b)) == 0
-            self.pairs.append((a, b))
-        self.used = 0
+        self.free, self.used = [], {}
         self.enabled = False
 
-    def provider(self):
-        if not self.enabled or self.used >= len(self.pairs):
+    def _pair(self):
+        if self.free:
+            return self.free.pop()
+        a, b = ctypes.c_void_p(), ctypes.c_void_p()
+        assert self.hip.hipEventCreate(ctypes.byref(a)) == 0 and self.hip.hipEventCreate(ctypes.byref(b)) == 0
+        return (a, b)
+
+    def provider(self, kind):
+        if not self.enabled:
             return (0, 0)
-        a, b = self.pairs[self.used]
-        self.used += 1
+        a, b = self._pair()
+        self.used.setdefault(kind, []).append((a, b))
         return (a.value, b.value)
 
-    def durations_ms(self):
-        out = []
-        for a, b in self.pairs[:self.used]:
-            ms = ctypes.c_float()
-            if self.hip.hipEventElapsedTime(ctypes.byref(ms), a, b) == 0:
-                out.append(ms.value)
+    def drain_ms(self):
+        """{kind: [ms, ...]} of everything recorded so far (call after a synchronize); recycles the events."""
+        out = {}
+        for kind, pairs in self.used.items():
+            vals = []
+            for a, b in pairs:
+                ms = ctypes.c_float()
+                if self.hip.hipEventElapsedTime(ctypes.byref(ms), a, b) == 0:
+                    vals.append(ms.value)
+            out[kind] = vals
+            self.free.extend(pairs)
+        self.used = {}
         return out
 
     def close(self):
-        for a, b in self.pairs:
+        for a, b in self.free + [p for ps in self.used.values() for p in ps]:
             self.hip.hipEventDestroy(a)
             self.hip.hipEventDestroy(b)
 
@@ -83,39 +110,224 @@ def log(msg):
     print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
 
 
-CPU_CALLS = 5   # of the 10 teacher-forced calls of one iteration (each call costs the same)
-CPU_TRAJ = 4    # trajectories in the CPU sample
+# ---------------------------------------------------------------------------------------------- CPU baseline
+def cpu_info():
+    model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    physical = None
+    try:
+        import psutil
+        physical = psutil.cpu_count(logical=False)
+    except Exception:
+        pass
+    return model, affinity, physical
 
 
-def cpu_baseline(cfg, sd, pos, a, u, threads):
-    """Oracle (CPU restatement == reference algorithm) on a bounded sample of the bench workload:
-    CPU_TRAJ trajectories, the first CPU_CALLS of their 10 teacher-forced model calls, forward +
-    backward (sized for roughly 10-30 s on the GPU host).  The iteration is 10 calls of identical
-    cost, so time(trajectory) = time(sample) / CPU_TRAJ * 10/CPU_CALLS."""
+def cpu_baseline(cfg, sd, pos, a, u, batch, iters, rollouts):
+    """BASELINE.md §3 protocol on the oracle (CPU restatement == the reference's algorithm): config C1 (`batch` = 8
+    trajectories, fp32), 1 warm-up + `iters` timed FULL exp_ns iterations (10 teacher-forced calls, summed rel-L2,
+    backward, AdamW wd=1e-5, OneCycleLR step), then `rollouts` timed 20-step prediction-feedback rollouts (B=1,
+    no grad).  Returns a dict (mean and best) plus the warm-up iteration's predictions for the GPU-vs-CPU rel-L2."""
     from oracle import transolver_oracle as orc
+    model, affinity, physical = cpu_info()
+    threads = max(1, min(affinity, physical or affinity))
     torch.set_num_threads(threads)
     sdo = orc.to_torch(sd, torch.float32, requires_grad=True)
-    x, fx, yy = (torch.from_numpy(np.ascontiguousarray(t[:CPU_TRAJ])) for t in (pos, a, u))
-    t0 = time.perf_counter()
-    loss, full, pred, grads = orc.train_iteration(sdo, x, fx, yy[..., :CPU_CALLS], cfg)
-    dt = time.perf_counter() - t0
-    return dt, pred, float(loss)
-
-
-CPU_ROLLOUT_STEPS = 4
-
-
-def cpu_rollout_baseline(cfg, sd, pos, a, threads):
-    """Oracle prediction-feedback loop (ns_vorticity_unrolling.py:264-286) on the CPU: one trajectory,
-    CPU_ROLLOUT_STEPS steps, no grad.  Returns steps/s."""
-    from oracle import transolver_oracle as orc
-    torch.set_num_threads(threads)
-    sdo = orc.to_torch(sd, torch.float32)
-    x, fx = (torch.from_numpy(np.ascontiguousarray(t[:1])) for t in (pos, a))
-    with torch.no_grad():
+    live = [k for k in sdo if k != "placeholder"]
+    opt = torch.optim.AdamW([sdo[k] for k in live], lr=1e-3, weight_decay=1e-5)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-3, total_steps=iters + 4)
+    x, fx, yy = (torch.from_numpy(np.ascontiguousarray(t[:batch])) for t in (pos, a, u))
+    times, pred0 = [], None
+    for it in range(iters + 1):
         t0 = time.perf_counter()
-        orc.rollout(sdo, x, fx, cfg, CPU_ROLLOUT_STEPS)
-        return CPU_ROLLOUT_STEPS / (time.perf_counter() - t0)
+        opt.zero_grad()
+        loss, full, pred, grads = orc.train_iteration(sdo, x, fx, yy, cfg)
+        for k in live:
+            sdo[k].grad = grads[k]
+        opt.step()
+        sched.step()
+        dt = time.perf_counter() - t0
+        if it == 0:
+            pred0 = pred          # initial weights: comparable with the GPU parity sample
+        else:
+            times.append(dt)
+        log(f"cpu oracle iteration {it}/{iters} ({'warm-up' if it == 0 else 'timed'}): {dt:.1f} s")
+        del grads, loss, full
+    sd_r = orc.to_torch(sd, torch.float32)
+    rtimes = []
+    with torch.no_grad():
+        orc.rollout(sd_r, x[:1], fx[:1], cfg, 2)                     # warm-up
+        for _ in range(rollouts):
+            t0 = time.perf_counter()
+            orc.rollout(sd_r, x[:1], fx[:1], cfg, 20)
+            rtimes.append(time.perf_counter() - t0)
+    out = {"value": round(batch / float(np.mean(times)), 5), "unit": "samples/s", "cores": threads, "kind": "port",
+           "best": round(batch / float(np.min(times)), 5), "cpu_model": model, "cpu_affinity": affinity,
+           "cpu_physical_cores": physical,
+           "sample": f"BASELINE.md §3 protocol: config C1 (B={batch}, fp32, 8 layers, C=256, M=64), 1 warm-up + {iters} "
+                     f"timed full exp_ns iterations (10 calls fwd+bwd+AdamW+OneCycle), torch CPU, {threads} threads: "
+                     f"{', '.join(f'{t:.1f}' for t in times)} s",
+           "rollout_steps_per_s_b1": round(20.0 / float(np.mean(rtimes)), 3),
+           "rollout_steps_per_s_b1_best": round(20.0 / float(np.min(rtimes)), 3),
+           "rollout_sample": f"{rollouts} timed 20-step prediction-feedback rollouts of one trajectory, no grad: "
+                             f"{', '.join(f'{t:.2f}' for t in rtimes)} s"}
+    return out, pred0
+
+
+# ---------------------------------------------------------------------------------------------- launching
+def self_launch(ngpus):
+    """Start `python -m torch.distributed.run --nproc-per-node N bench.py <same argv>` as a CHILD process (never an
+    exec: the ranks are fresh processes, the parent only waits), relay rank 0's JSON line on stdout and return the
+    children's exit code."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={ngpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log(f"self-launch: {' '.join(cmd)}")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    for line in proc.stdout:           # the ranks log to stderr (inherited); stdout carries rank 0's JSON line
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
+class Ranks:
+    """Process-group context of this rank + the barrier-bracketed timer of the driver contract."""
+
+    def __init__(self, gpus):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if gpus != self.world:
+            raise SystemExit(f"--gpus {gpus} but WORLD_SIZE={self.world}: launch with --nproc-per-node {gpus}")
+        self.backend = os.environ.get("PA2D_DIST_BACKEND", "nccl") if self.world > 1 else None
+        ndev = torch.cuda.device_count()
+        if self.world > 1 and self.backend == "nccl" and ndev < self.world:
+            raise SystemExit(f"{self.world} ranks over RCCL need {self.world} visible GPUs, found {ndev} "
+                             "(PA2D_DIST_BACKEND=gloo rehearses the N>1 code path with ranks sharing a GPU)")
+        if self.world > 1 and self.backend != "nccl":
+            local_rank = local_rank % max(ndev, 1)       # rehearsal mode: ranks share the visible GPU(s)
+        torch.cuda.set_device(local_rank)
+        self.dev = torch.device("cuda", local_rank)
+        if self.world > 1:
+            # "nccl" is RCCL on ROCm.  PA2D_DIST_BACKEND=gloo exists only to rehearse the N>1 code path on a box with
+            # a single GPU (several ranks sharing cuda:0); it is never used for reported numbers.
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev)
+            else:
+                dist.init_process_group(self.backend)
+
+    def barrier(self):
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(self, fn, steps, before_step=None):
+        """Time exactly `steps` calls of fn bracketed by barrier + synchronize; MAX over ranks."""
+        self.barrier()
+        t0 = time.perf_counter()
+        out = None
+        for i in range(steps):
+            if before_step is not None:
+                before_step(i)
+            out = fn()
+        self.barrier()
+        dt = time.perf_counter() - t0
+        if self.world > 1:
+            tt = torch.tensor([dt], device=self.dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, out
+
+    def close(self):
+        if self.world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+
+
+def rooflines(ms_by_kind, engine, rows, C, traffic=None):
+    """(roofline, roofline_hbm) dicts from the live HIP-event durations of one workload (rows = B*N)."""
+    roof = hbm = None
+    conv = ms_by_kind.get("conv") or []
+    if conv:
+        flops = 2.0 * rows * (9 * C) * (2 * C)
+        avg = float(np.mean(conv))
+        kernel, peak = CONV_KERNELS[engine]
+        ach = flops / (avg * 1e-3) / 1e12
+        roof = {"bound": "mfma", "kernel": kernel, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(ach / peak, 4), "traffic": traffic["bytes"] if traffic else None,
+                "traffic_source": traffic["source"] if traffic else None,
+                "launches_timed": len(conv), "avg_launch_ms": round(avg, 4), "flops_per_launch": flops,
+                "peak_note": ("fp32-equivalent: dense bf16 MFMA peak / 6 terms" if engine == ops.ENGINE_SPLIT else
+                              ("dense bf16 MFMA" if engine == ops.ENGINE_BF16 else "fp32 MFMA"))}
+    kernels, tot_b, tot_ms = [], 0.0, 0.0
+    for kind, (kname, units) in HBM_KERNELS.items():
+        ms = ms_by_kind.get(kind) or []
+        if not ms:
+            continue
+        nbytes = units * rows * C * 4.0
+        avg = float(np.mean(ms))
+        gbs = nbytes / (avg * 1e-3) / 1e9
+        kernels.append({"kernel": kname, "bytes_per_launch": nbytes, "avg_launch_ms": round(avg, 4),
+                        "launches_timed": len(ms), "achieved": round(gbs, 1), "frac": round(gbs / PEAK_HBM_GBS, 4)})
+        tot_b += nbytes * len(ms)
+        tot_ms += float(np.sum(ms))
+    if kernels:
+        ach = tot_b / (tot_ms * 1e-3) / 1e9
+        hbm = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+               "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
+               "note": "launch-weighted over the three slice-path kernels; algorithmic bytes per launch = "
+                       "2 / 2 / 5 x R*C*4 B (DESIGN.md §4)", "kernels": kernels}
+    return roof, hbm
+
+
+def darcy_leg(rk, pool, engine, batch, steps):
+    """BASELINE configs[4]: one exp_darcy.py iteration (single model call, decode, rel-L2 + 0.1 x derivative loss,
+    backward, clip 0.1, AdamW + OneCycleLR) on 421x421, 8 layers, C=128, 8 heads, M=128, batch per GPU `batch`."""
+    cfg = synth.DARCY_CONFIG
+    s = cfg["H"]
+    model = harness.build_model(cfg, synth.synth_state_dict(cfg, seed=7), rk.dev, engine=engine).train()
+    opt = FusedAdamW(model.parameters(), lr=1e-3, weight_decay=1e-5, max_grad_norm=0.1)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-3, total_steps=steps + 8)
+    pos, coeff, sol = synth.darcy_batch(batch, s, seed=300 + rk.rank)
+    xn, yn = UnitTransformer(torch.from_numpy(coeff)), UnitTransformer(torch.from_numpy(sol))
+    x = torch.from_numpy(pos).to(rk.dev)
+    fx = xn.encode(torch.from_numpy(coeff)).to(rk.dev)
+    y = yn.encode(torch.from_numpy(sol)).to(rk.dev)
+    yn.to(rk.dev)
+
+    def step():
+        return harness.darcy_train_step(model, opt, sched, x, fx, y, yn, 1.0 / s, s, grad_sync=opt.sync)
+
+    step()
+    step()
+    pool.enabled = True
+    dt, (loss, l2, _) = rk.timed(step, steps)
+    pool.enabled = False
+    roof, hbm = rooflines(pool.drain_ms(), engine, batch * s * s, cfg["n_hidden"])
+    fwd_gflop = 1143.0          # SURVEY §8(d) table: forward GFLOP per sample per call at this geometry
+    out = {"workload": f"exp_darcy.py iteration, Darcy 421x421 (N=177241), Transolver_Structured_Mesh_2D 8 layers, "
+                       f"C=128, 8 heads, M=128 slices, batch {batch}/GPU (BASELINE configs[4] geometry), "
+                       f"engine {ENGINE_LABEL[engine]}",
+           "value": round(rk.world * batch * steps / dt, 3), "unit": "samples/s", "ms_per_iter": round(1e3 * dt / steps, 2),
+           "steps": steps, "achieved_tflops_fwd_bwd": round(3 * fwd_gflop * batch * steps / dt / 1e3, 1),
+           "final_l2_per_sample": round(float(l2) / batch, 5), "roofline": roof, "roofline_hbm": hbm}
+    del model, opt
+    torch.cuda.empty_cache()
+    return out
 
 
 def main():
@@ -124,72 +336,66 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch-per-gpu", type=int, default=32)
+    ap.add_argument("--engine", default=None, choices=[None, "f32", "split", "bf16"],
+                    help="GEMM engine of the measured model (default: PA2D_GEMM or the fp32-accurate split engine)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=8, help="trajectories of the CPU protocol iteration (config C1: 8)")
+    ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--no-rollout", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="replay forward+backward from one hipGraph (launch-bound small batches); disables the per-kernel HIP events")
     ap.add_argument("--fold-time", action="store_true",
                     help="run the 10 teacher-forced calls of an iteration as ONE call on 10*B windows (same loss and gradients)")
     ap.add_argument("--no-folded-leg", action="store_true", help="skip the secondary time-folded measurement")
-    ap.add_argument("--no-split-leg", action="store_true", help="skip the secondary split-engine measurement")
+    ap.add_argument("--no-exact-leg", "--no-split-leg", dest="no_exact_leg", action="store_true",
+                    help="skip the secondary exact-fp32-MFMA-engine measurement")
+    ap.add_argument("--no-darcy-leg", action="store_true", help="skip the Darcy 421x421 (BASELINE configs[4]) leg")
+    ap.add_argument("--darcy-batch", type=int, default=2)
+    ap.add_argument("--roofline-steps", type=int, default=4,
+                    help="timed steps (from the first) whose conv / slice kernels carry HIP events")
     ap.add_argument("--torch-optim", action="store_true", help="torch.optim.AdamW + torch rel-L2 instead of the fused kernels")
-    ap.add_argument("--gemm-mode", type=int, default=0,
-                    help="0 = exact fp32 MFMA (the metric of record), 2 = bf16-compute mode (BASELINE configs[2] numerics)")
     args = ap.parse_args()
-    from transformerbasednavierstokesolver_amd import _lib
-    _lib.load().pa2d_set_gemm_mode(args.gemm_mode)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: this process has not touched the GPU (no torch.cuda call,
+        # libpa2d not loaded) and never will — it starts N fresh ranks and relays their output.
+        raise SystemExit(self_launch(args.gpus))
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N>1 must be launched with `python -m torch.distributed.run --nproc-per-node N`")
-    ndev = torch.cuda.device_count()
-    if world > 1 and os.environ.get("PA2D_DIST_BACKEND", "nccl") != "nccl":
-        local_rank = local_rank % max(ndev, 1)       # rehearsal mode: ranks share the visible GPU(s)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        # "nccl" is RCCL on ROCm.  PA2D_DIST_BACKEND=gloo exists only to rehearse the N>1 code path on a
-        # box with a single GPU (several ranks sharing cuda:0); it is never used for reported numbers.
-        backend = os.environ.get("PA2D_DIST_BACKEND", "nccl")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
-
+    rk = Ranks(args.gpus)
+    world, rank, dev = rk.world, rk.rank, rk.dev
+    engine = ops.resolve_engine(args.engine)
     cfg = synth.NS_CONFIG
     B = args.batch_per_gpu
     sd = synth.synth_state_dict(cfg, seed=0)          # identical on every rank
-    model = harness.build_model(cfg, sd, dev).train()
+    model = harness.build_model(cfg, sd, dev, engine=engine).train()
     total_steps = args.steps + args.warmup
-    if args.torch_optim:
-        opt = torch.optim.AdamW(model.parameters(), lr=1e-3, weight_decay=1e-5)
-        loss_fn = TestLoss(size_average=False)
-    else:   # fused multi-tensor AdamW + fused rel-L2 (libpa2d), same arithmetic
-        opt = FusedAdamW(model.parameters(), lr=1e-3, weight_decay=1e-5)
-        loss_fn = FusedTestLoss(size_average=False)
-    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-3, total_steps=3 * max(total_steps, 2) + 6)
-    log(f"rank {rank}/{world}: model built, generating {B} synthetic trajectories")
+
+    def make_optim(m):
+        if args.torch_optim:
+            o = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-5)
+            return o, ddp.FlatGradSync(m.parameters()), TestLoss(size_average=False)
+        o = FusedAdamW(m.parameters(), lr=1e-3, weight_decay=1e-5)    # fused multi-tensor AdamW + fused rel-L2 (§8(f)-1)
+        return o, o.sync, FusedTestLoss(size_average=False)
+
+    opt, sync, loss_fn = make_optim(model)
+    sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-3, total_steps=4 * max(total_steps, 2) + 12)
+    log(f"rank {rank}/{world}: model built (engine {engine}), generating {B} synthetic trajectories")
     pos, a, u = synth.ns_batch(B, seed=100 + rank)    # this rank's shard of the global batch
     x, fx, yy = (torch.from_numpy(t).to(dev) for t in (pos, a, u))
-    sync = ddp.FlatGradSync(model.parameters()) if args.torch_optim else opt.sync
+    calls = yy.shape[-1]
+    N, C = cfg["H"] * cfg["W"], cfg["n_hidden"]
 
-    # parity sample before the weights move: teacher-forced predictions with the initial weights
-    # (run at the full batch so that every launch of the dominant kernel in this process has the
-    # same shape and the rocprofv3 per-kernel average is comparable with the live HIP-event average)
+    # parity sample before the weights move: teacher-forced predictions with the initial weights (full batch, so
+    # every launch of the dominant kernel in this process has the same shape and the rocprofv3 per-kernel average
+    # is comparable with the live HIP-event average)
     with torch.no_grad():
         _, _, pred_gpu0 = harness.train_iteration(model, x, fx, yy)
-    pred_gpu0 = pred_gpu0[:CPU_TRAJ].cpu()
+    pred_gpu0 = pred_gpu0[:args.cpu_batch].cpu()
 
-    layers, calls = cfg["n_layers"], yy.shape[-1]
-    pool = HipEventPool(args.steps * layers * calls * 2 + 8)
-    ops.conv_event_provider = pool.provider
-
+    pool = HipEventPool()
     if args.graph:
-        ops.conv_event_provider = None
         graphed = harness.GraphedTrainStep(model, opt, sched, x, fx, yy, loss_fn=loss_fn, fold_time=args.fold_time)
+    else:
+        ops.event_provider = pool.provider
 
     def step():
         if args.graph:
@@ -200,64 +406,43 @@ def main():
         step()
         torch.cuda.synchronize()
         log(f"warmup step {i + 1}/{args.warmup} done")
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    pool.enabled = True
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss, full = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+
+    def gate(i):
+        pool.enabled = i < args.roofline_steps
+    dt, (loss, full) = rk.timed(step, args.steps, before_step=gate)
     pool.enabled = False
     log(f"{args.steps} timed steps in {dt:.2f} s")
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
 
-    conv_ms = pool.durations_ms()
-    N = cfg["H"] * cfg["W"]
-    C = cfg["n_hidden"]
-    conv_flops = 2.0 * (B * (calls if args.fold_time else 1) * N) * (9 * C) * (2 * C)
-    roof = None
-    if conv_ms:
-        avg_ms = float(np.mean(conv_ms))
-        achieved = conv_flops / (avg_ms * 1e-3) / 1e12
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "conv_pmc_traffic.json")
-        if os.path.exists(pmc) and B == 32 and not args.fold_time and args.gemm_mode == 0:   # measured on that launch shape
-            try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        # exact engine: fp32 MFMA peak.  Split engine: 6 bf16 MFMA terms per fp32 product -> fp32-equivalent peak =
-        # dense bf16 peak / 6.  bf16-compute mode: dense bf16 MFMA peak.
-        kernel, peak = {0: (CONV_KERNEL, PEAK_FP32_MFMA_TFLOPS),
-                        1: ("gemm_kc_split_kernel<128,128,true,3,true>", round(PEAK_BF16_MFMA_TFLOPS / 6, 1)),
-                        2: ("gemm_kc_split_kernel<128,128,true,1,true>", PEAK_BF16_MFMA_TFLOPS)}[args.gemm_mode]
-        roof = {"bound": "mfma", "kernel": kernel, "achieved": round(achieved, 2), "peak": peak,
-                "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
-                "launches_timed": len(conv_ms), "avg_launch_ms": round(avg_ms, 4),
-                "flops_per_launch": conv_flops}
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "conv_pmc_traffic.json")
+    if os.path.exists(pmc) and B == 32 and not args.fold_time:
+        try:      # PMC passes are a separate rocprofv3 run (they cannot ride in the timed region): static, labelled
+            rec = json.load(open(pmc))
+            if rec.get("engine", "f32") == {0: "f32", 1: "split", 2: "bf16"}[engine]:
+                traffic = {"bytes": rec.get("hbm_bytes_per_launch"),
+                           "source": "profiles/conv_pmc_traffic.json (static: rocprofv3 --pmc passes of this kernel "
+                                     "and launch shape, not measured in this run)"}
+        except Exception:
+            traffic = None
+    roof, roof_hbm = rooflines(pool.drain_ms(), engine, B * (calls if args.fold_time else 1) * N, C, traffic)
 
     out = {
         "metric": "ns64_train_samples_per_s", "value": round(world * B * args.steps / dt, 4), "unit": "samples/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 2),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.gemm_mode == 0 else ("f32 via 6-term bf16 split (conv)" if args.gemm_mode == 1 else "bf16 MFMA compute, f32 accumulate+storage"), "data": "synthetic",
+        "n_gpus": world,
+        "rccl_ranks": (dist.get_world_size() if world > 1 and rk.backend == "nccl" else (1 if world == 1 else 0)),
+        "dist_backend": rk.backend, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if engine != ops.ENGINE_BF16 else "bf16 MFMA compute, f32 accumulate+storage", "data": "synthetic",
         "config": {"workload": "exp_ns.py training iteration on NS 64x64 (10 teacher-forced Transolver calls + "
                                "backward + AdamW/OneCycleLR): Transolver_Structured_Mesh_2D 8 layers, C=256, 8 heads, "
                                f"M=64 slices, fp32, batch {B}/GPU (BASELINE configs[1])",
+                   "gemm_engine": ENGINE_LABEL[engine],
                    "global_batch": world * B, "batch_per_gpu": B, "parallelism": f"dp{world}",
                    "model_calls_per_step": calls, "grad_allreduce_bytes": sync.nbytes,
                    "hipgraph_training_step": bool(args.graph), "time_folded_calls": bool(args.fold_time)},
         "model_call_samples_per_s": round(world * B * args.steps * calls / dt, 2),
         "final_loss_per_sample_call": round(float(loss) / B / calls, 5),
-        "roofline": roof,
+        "roofline": roof, "roofline_hbm": roof_hbm,
     }
 
     if not (args.fold_time or args.graph or args.no_folded_leg):
@@ -267,106 +452,69 @@ def main():
         def fstep():
             return harness.train_step(model, opt, sched, x, fx, yy, grad_sync=sync, loss_fn=loss_fn, fold_time=True)
         fstep()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            fstep()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        fd = time.perf_counter() - t1
-        if world > 1:
-            tf_ = torch.tensor([fd], device=dev, dtype=torch.float64)
-            dist.all_reduce(tf_, op=dist.ReduceOp.MAX)
-            fd = float(tf_.item())
-        out["time_folded"] = {"value": round(world * B * args.steps / fd, 4), "unit": "samples/s",
-                              "ms_per_step": round(1e3 * fd / args.steps, 2),
+        fsteps = min(args.steps, 5)
+        fd, _ = rk.timed(fstep, fsteps)
+        out["time_folded"] = {"value": round(world * B * fsteps / fd, 4), "unit": "samples/s",
+                              "ms_per_step": round(1e3 * fd / fsteps, 2), "steps": fsteps,
                               "note": "10 teacher-forced calls run as one call on 10*B windows (caller-side change)"}
         log(f"time-folded leg: {out['time_folded']['value']} samples/s")
 
-    if args.gemm_mode == 0 and not (args.fold_time or args.graph or args.no_split_leg):
-        # Secondary leg, reported next to (never instead of) `value`: the same sequential iteration with the conv
-        # GEMMs on the fp32-accurate 6-term bf16-split engine (pa2d_set_gemm_mode(1); passes the same fp32 parity
-        # tolerances, tests/test_gpu_model.py::test_split_engine_full_ns_model_meets_fp32_tolerances).
-        lib = _lib.load()
-        lib.pa2d_set_gemm_mode(1)
-        try:
-            def sstep():
-                return harness.train_step(model, opt, sched, x, fx, yy, grad_sync=sync, loss_fn=loss_fn)
-            sstep()
-            torch.cuda.synchronize()
-            if world > 1:
-                dist.barrier()
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                sstep()
-            torch.cuda.synchronize()
-            if world > 1:
-                dist.barrier()
-            sd_ = time.perf_counter() - t1
-        finally:
-            lib.pa2d_set_gemm_mode(0)
-        if world > 1:
-            ts_ = torch.tensor([sd_], device=dev, dtype=torch.float64)
-            dist.all_reduce(ts_, op=dist.ReduceOp.MAX)
-            sd_ = float(ts_.item())
-        out["fp32_split_engine"] = {"value": round(world * B * args.steps / sd_, 4), "unit": "samples/s",
-                                    "ms_per_step": round(1e3 * sd_ / args.steps, 2),
-                                    "note": "conv GEMMs as 6 bf16 MFMA terms of an exact hi+mid+lo operand split, fp32 "
-                                            "accumulate (fp32-level accuracy); opt-in engine, not the metric of record"}
-        log(f"split-engine leg: {out['fp32_split_engine']['value']} samples/s")
+    if engine != ops.ENGINE_F32 and not (args.fold_time or args.graph or args.no_exact_leg):
+        # Secondary leg: the same sequential iteration on the exact-fp32-MFMA engine (every GEMM on
+        # v_mfma_f32_32x32x2_f32) — a second model + optimizer on the same weights and data, own engine argument.
+        m2 = harness.build_model(cfg, sd, dev, engine="f32").train()
+        o2, s2, l2 = make_optim(m2)
+
+        def estep():
+            return harness.train_step(m2, o2, None, x, fx, yy, grad_sync=s2, loss_fn=l2)
+        estep()
+        esteps = min(args.steps, 5)
+        pool.enabled = True
+        ed, _ = rk.timed(estep, esteps)
+        pool.enabled = False
+        eroof, _ = rooflines(pool.drain_ms(), ops.ENGINE_F32, B * N, C)
+        out["fp32_exact_engine"] = {"value": round(world * B * esteps / ed, 4), "unit": "samples/s",
+                                    "ms_per_step": round(1e3 * ed / esteps, 2), "steps": esteps, "roofline": eroof,
+                                    "note": "every GEMM on v_mfma_f32_32x32x2_f32 (engine f32); same weights, data, loop"}
+        log(f"exact-engine leg: {out['fp32_exact_engine']['value']} samples/s")
+        del m2, o2, s2
+        torch.cuda.empty_cache()
 
     if not args.no_rollout:
         # unrolled-inference steps/s (ns_vorticity_unrolling.py:264-286), hipGraph-captured step.  Replicas
         # only: every rank rolls out its own trajectories, no communication; the aggregate is
         # N * batch * 20 frames / (max over ranks of the time of 20 steps).
+        ops.event_provider = None
         model.eval()
         for bsz, tag in ((B, f"b{B}"), (1, "b1")):
             gr = harness.GraphedRollout(model, x[:bsz], fx[:bsz])
             gr.run(fx[:bsz], 2)
-            torch.cuda.synchronize()
-            if world > 1:
-                dist.barrier()
-            t1 = time.perf_counter()
-            gr.run(fx[:bsz], 20)
-            torch.cuda.synchronize()
-            d = time.perf_counter() - t1
-            if world > 1:
-                td = torch.tensor([d], device=dev, dtype=torch.float64)
-                dist.all_reduce(td, op=dist.ReduceOp.MAX)
-                d = float(td.item())
+            d, _ = rk.timed(lambda: gr.run(fx[:bsz], 20), 1)
             out[f"rollout_steps_per_s_{tag}"] = round(20 / d, 2)                 # per replica
             out[f"rollout_frames_per_s_{tag}"] = round(world * 20 * bsz / d, 2)  # aggregate over all replicas
             if rank == 0:
                 log(f"rollout {tag}: {20 / d:.1f} steps/s per replica, {world * 20 * bsz / d:.0f} frames/s aggregate")
             del gr
+        model.train()
 
+    if not args.no_darcy_leg:
+        ops.event_provider = pool.provider
+        torch.cuda.empty_cache()
+        out["darcy421"] = darcy_leg(rk, pool, engine, args.darcy_batch, min(max(args.steps, 3), 5))
+        log(f"darcy421 leg: {out['darcy421']['ms_per_iter']} ms/iter, {out['darcy421']['value']} samples/s")
+
+    ops.event_provider = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        threads = max(1, min(threads, 16))       # a 1-GPU box owns a 16-core share
-        log(f"cpu baseline: oracle on {threads} threads ...")
-        cdt, pred_cpu, closs = cpu_baseline(cfg, sd, pos, a, u, threads)
-        it_s = cdt * calls / CPU_CALLS / min(CPU_TRAJ, B)
-        pg = pred_gpu0[..., :CPU_CALLS].double()
-        rel = float((pg - pred_cpu.double()).norm() / pred_cpu.double().norm())
-        out["cpu_baseline"] = {"value": round(1.0 / it_s, 5), "unit": "samples/s", "cores": threads, "kind": "port",
-                               "sample": f"{min(CPU_TRAJ, B)} trajectories, {CPU_CALLS} of the {calls} teacher-forced model "
-                                         f"calls of one exp_ns iteration, forward+backward, fp32 torch CPU, "
-                                         f"{threads} threads: {cdt:.1f} s measured -> {it_s:.2f} s per trajectory"}
-        out["rel_l2_gpu_vs_cpu_oracle"] = rel
-        if not args.no_rollout:
-            rs = cpu_rollout_baseline(cfg, sd, pos, a, threads)
-            out["cpu_baseline"]["rollout_steps_per_s_b1"] = round(rs, 3)
-            out["cpu_baseline"]["rollout_sample"] = f"{CPU_ROLLOUT_STEPS} autoregressive steps of one trajectory, no grad"
-            log(f"CPU oracle rollout: {rs:.2f} steps/s at B=1")
+        log("cpu baseline: oracle by the BASELINE.md §3 protocol ...")
+        cb = min(args.cpu_batch, B)
+        rec, pred_cpu = cpu_baseline(cfg, sd, pos, a, u, cb, args.cpu_iters, 3)
+        out["cpu_baseline"] = rec
+        out["rel_l2_gpu_vs_cpu_oracle"] = float((pred_gpu0[:cb].double() - pred_cpu.double()).norm() / pred_cpu.double().norm())
+        log(f"CPU oracle: {rec['value']} samples/s, rollout {rec['rollout_steps_per_s_b1']} steps/s at B=1")
     pool.close()
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    rk.close()
 
 
 if __name__ == "__main__":

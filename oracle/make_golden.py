@@ -308,6 +308,53 @@ def g6_irregular():
     np.savez(os.path.join(GOLD, "G6_irregular.npz"), **out)
 
 
+G7_CASES = {"s1n3": dict(fun_dim=4, out_dim=1, step=1, n=3, seed=71),       # scalar field, 3 chained calls
+            "s2n2": dict(fun_dim=6, out_dim=2, step=2, n=2, seed=73)}       # 2-component field, window moves by 2
+
+
+def g7_sol_wrapper(SOL, TestLoss):
+    """The reference's autoregressive wrapper (model/SOL_Transolver_Structured_Mesh_2D.py:47-52) itself: `n` chained
+    calls with prediction feedback, loss on the LAST prediction, backward through the whole chain (BPTT) — output
+    and every parameter gradient, fp64 and fp32.  Pins `oracle.sol_forward` and, through it, the HIP SOL class."""
+    out = {}
+    for tag, c in G7_CASES.items():
+        cfg = dict(synth.TINY_CONFIG, fun_dim=c["fun_dim"], out_dim=c["out_dim"])
+        sd = synth.synth_state_dict(cfg, seed=c["seed"])
+        B, N = 2, cfg["H"] * cfg["W"]
+        rng = np.random.default_rng(c["seed"] + 1)
+        x = rng.standard_normal((B, N, 2)).astype(np.float32)
+        fx = rng.standard_normal((B, N, cfg["fun_dim"])).astype(np.float32)
+        y = rng.standard_normal((B, N, cfg["out_dim"])).astype(np.float32)
+        out.update({f"{tag}.x": x, f"{tag}.fx": fx, f"{tag}.y": y})
+        for dtype, dt, tol in ((torch.float64, "f64", 1e-12), (torch.float32, "f32", 2e-5)):
+            m = SOL(space_dim=cfg["space_dim"], n_layers=cfg["n_layers"], n_hidden=cfg["n_hidden"], dropout=0.0,
+                    n_head=cfg["n_head"], Time_Input=False, act=cfg["act"], mlp_ratio=cfg["mlp_ratio"],
+                    fun_dim=cfg["fun_dim"], out_dim=cfg["out_dim"], slice_num=cfg["slice_num"], ref=cfg["ref"],
+                    unified_pos=cfg["unified_pos"], H=cfg["H"], W=cfg["W"], step=c["step"], look_ahead=c["n"])
+            res = m.transolver_model.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}, strict=True)
+            assert not res.missing_keys and not res.unexpected_keys
+            m = m.to(dtype)
+            m.transolver_model.pos = m.transolver_model.pos.to(dtype)
+            xt, fxt, yt = (torch.from_numpy(a).to(dtype) for a in (x, fx, y))
+            pred = m(xt, fxt)
+            loss = TestLoss(size_average=False)(pred.reshape(B, -1), yt.reshape(B, -1))
+            loss.backward()
+            sdo = orc.to_torch(sd, dtype, requires_grad=True)
+            po = orc.sol_forward(sdo, xt, fxt, cfg, c["n"], step=c["step"])
+            lo = orc.rel_l2(po.reshape(B, -1), yt.reshape(B, -1))
+            lo.backward()
+            check(f"G7 {tag} {dt} forward", po.detach(), pred.detach(), tol)
+            out[f"{tag}.pred.{dt}"] = pred.detach().numpy()
+            out[f"{tag}.loss.{dt}"] = np.asarray(loss.item())
+            for k, p in m.transolver_model.named_parameters():
+                if p.grad is None:
+                    assert k == "placeholder" and sdo[k].grad is None
+                    continue
+                check(f"G7 {tag} {dt} grad {k}", sdo[k].grad, p.grad, tol * 50)
+                out[f"{tag}.grad.{dt}.{k}"] = p.grad.numpy()
+    np.savez_compressed(os.path.join(GOLD, "G7_sol_wrapper.npz"), **out)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     torch.manual_seed(0)
@@ -315,7 +362,8 @@ def main():
     for name, fn in (("G1", lambda: g1_tiny(Model, TestLoss)), ("G1b", lambda: g1b_tiny_branches(Model)),
                      ("G2", lambda: g2_attn(Attn)), ("G3", lambda: g3_shipped_rollout(Model)),
                      ("G4", lambda: g4_train_iteration(Model, TestLoss)),
-                     ("G5", lambda: g5_full_ns(Model, TestLoss)), ("G6", g6_irregular)):
+                     ("G5", lambda: g5_full_ns(Model, TestLoss)), ("G6", g6_irregular),
+                     ("G7", lambda: g7_sol_wrapper(SOL, TestLoss))):
         if len(sys.argv) > 1 and name not in sys.argv[1:]:
             continue
         print(name)

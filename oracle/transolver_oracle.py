@@ -314,7 +314,7 @@ def darcy_loss(out, y, mean, std, dx, s):
     out, y = out * std + mean, y * std + mean
     l2 = rel_l2(out, y)
     B = out.shape[0]
-    mask = torch.zeros(s, s, dtype=out.dtype)
+    mask = torch.zeros(s, s, dtype=out.dtype, device=out.device)
     mask[1:-1, 1:-1] = 1
     inner = (out.reshape(B, s, s) * mask).reshape(B, s * s, 1)
     gx, gy = central_diff(y.unsqueeze(-1), dx, s)

@@ -42,7 +42,7 @@ def _data():
     return torch.randn(8, 5, 6, generator=g), torch.randn(8, 5, 1, generator=g)
 
 
-def _worker(rank, world, port, out):
+def _worker(rank, world, port, out, set_to_none):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from transformerbasednavierstokesolver_amd import ddp
@@ -51,25 +51,28 @@ def _worker(rank, world, port, out):
     x, y = ddp.shard_batch(_data(), rank, world)
     sync = ddp.FlatGradSync(model.parameters())
     opt = torch.optim.AdamW(model.parameters(), lr=1e-2, weight_decay=1e-2)
-    for _ in range(2):                       # second step exercises the persistent flat-view path
-        opt.zero_grad(set_to_none=False)
+    for _ in range(3):                       # later steps exercise the persistent flat-view path
+        opt.zero_grad(set_to_none=set_to_none)      # True: autograd allocates fresh .grad tensors -> re-adopted
         _loss(model, x, y).backward()
         sync()
         opt.step()
     if rank == 0:
         torch.save({k: v.detach().clone() for k, v in model.state_dict().items()}, out)
-        assert model.placeholder.grad is None and sync.nbytes == 4 * (6 * 8 + 8 + 8 + 1)
+        assert model.placeholder.grad is None
+        assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(sync.params, sync.views) if p.grad is not None)
+        assert sync.nbytes == 4 * (8 + 6 * 8 + 8 + 8 + 4)     # eager bucket: every parameter, 16-byte slots
     dist.destroy_process_group()
 
 
-def test_two_rank_training_equals_single_process(tmp_path):
+@pytest.mark.parametrize("set_to_none", [False, True])
+def test_two_rank_training_equals_single_process(tmp_path, set_to_none):
     out = str(tmp_path / "ddp.pt")
-    mp.spawn(_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), out, set_to_none), nprocs=2, join=True)
     got = torch.load(out, weights_only=True)
     ref = Toy()
     opt = torch.optim.AdamW(ref.parameters(), lr=1e-2, weight_decay=1e-2)
     x, y = _data()
-    for _ in range(2):
+    for _ in range(3):
         opt.zero_grad()
         _loss(ref, x, y).backward()
         opt.step()
@@ -77,6 +80,30 @@ def test_two_rank_training_equals_single_process(tmp_path):
         assert torch.allclose(got[k], v, rtol=1e-5, atol=1e-7), k
     # the unused parameter saw neither gradient nor weight decay on either path
     assert torch.equal(got["placeholder"], Toy().placeholder.detach())
+
+
+def test_bucket_adopts_late_and_foreign_gradients():
+    """A parameter that first receives a gradient AFTER the bucket was built (placeholder when fx=None, time_fc when
+    T is passed later) is reduced and handed to the optimizer from then on; a foreign .grad tensor is copied in."""
+    from transformerbasednavierstokesolver_amd import ddp
+    model = Toy()
+    sync = ddp.FlatGradSync(model.parameters())
+    ip = sync.index_of(model.placeholder)
+    x, y = _data()
+    _loss(model, x, y).backward()
+    sync()
+    assert model.placeholder.grad is None and not sync.touched[ip]
+    runs = sync.active_ranges()
+    assert runs == [(8, sync.total)]                      # placeholder's slot [0, 8) is skipped
+    (model.placeholder.sum() * 2.0).backward()            # now it is used
+    sync()
+    assert sync.touched[ip] and model.placeholder.grad.data_ptr() == sync.views[ip].data_ptr()
+    assert torch.equal(sync.views[ip], torch.full((8,), 2.0))
+    assert sync.active_ranges() == [(0, sync.total)]
+    model.a.weight.grad = torch.ones_like(model.a.weight)          # foreign tensor (e.g. hand-set gradient)
+    sync()
+    ia = sync.index_of(model.a.weight)
+    assert model.a.weight.grad.data_ptr() == sync.views[ia].data_ptr() and float(sync.views[ia].min()) == 1.0
 
 
 def test_shard_batch_rejects_uneven_split():

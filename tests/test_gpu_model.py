@@ -130,13 +130,15 @@ def test_g4_training_iteration_and_optimizer_step():
         assert abs(float(p.detach().double().norm()) - float(g["param1.norm." + k])) < 1e-5 * float(g["param1.norm." + k]) + 1e-12, k
 
 
-def test_g5_full_ns_config_forward_backward():
-    """BASELINE configs[1] architecture: 8 layers, C=256, 8 heads, M=64, 64x64."""
+@pytest.mark.parametrize("engine", ["f32", "split"])
+def test_g5_full_ns_config_forward_backward(engine):
+    """BASELINE configs[1] architecture: 8 layers, C=256, 8 heads, M=64, 64x64 — on BOTH fp32-accurate engines (exact
+    fp32 MFMA, and the 6-term bf16 split that is the default) at the SAME fp32 tolerances."""
     from transformerbasednavierstokesolver_amd import synth, harness
     from transformerbasednavierstokesolver_amd.utils.testloss import TestLoss
     g = np.load(os.path.join(GOLDEN, "G5_full_ns.npz"))
     cfg = synth.NS_CONFIG
-    m = harness.build_model(cfg, synth.synth_state_dict(cfg, seed=51), DEV)
+    m = harness.build_model(cfg, synth.synth_state_dict(cfg, seed=51), DEV, engine=engine)
     pos, a, u = synth.ns_batch(1, seed=52)
     x, fx, y = (torch.from_numpy(t).to(DEV) for t in (pos, a, u[..., :1]))
     pred = m(x, fx=fx)
@@ -177,6 +179,35 @@ def test_sol_wrapper_bptt_matches_oracle():
         if k == "placeholder":
             continue
         assert rel_l2(p.grad, sdo[k].grad) < _grad_tol(k), k
+
+
+@pytest.mark.parametrize("tag,c", [("s1n3", dict(fun_dim=4, out_dim=1, step=1, n=3, seed=71)),
+                                   ("s2n2", dict(fun_dim=6, out_dim=2, step=2, n=2, seed=73))])
+def test_g7_sol_wrapper_against_the_reference_made_fixture(tag, c):
+    """HIP SOL wrapper vs G7 — output, loss and every gradient of the REFERENCE's SOL class (BPTT through n chained
+    calls, model/SOL_Transolver_Structured_Mesh_2D.py:47-52)."""
+    from transformerbasednavierstokesolver_amd import synth
+    from transformerbasednavierstokesolver_amd.model.SOL_Transolver_Structured_Mesh_2D import SOL_Transolver_Structured_Mesh_2D
+    from transformerbasednavierstokesolver_amd.utils.testloss import TestLoss
+    g = np.load(os.path.join(GOLDEN, "G7_sol_wrapper.npz"))
+    cfg = dict(synth.TINY_CONFIG, fun_dim=c["fun_dim"], out_dim=c["out_dim"])
+    kw = {k: cfg[k] for k in ("space_dim", "n_layers", "n_hidden", "dropout", "n_head", "Time_Input", "act", "mlp_ratio",
+                              "fun_dim", "out_dim", "slice_num", "ref", "unified_pos", "H", "W")}
+    sol = SOL_Transolver_Structured_Mesh_2D(**kw, step=c["step"], look_ahead=c["n"])
+    sol.transolver_model.load_state_dict({k: torch.from_numpy(v) for k, v in synth.synth_state_dict(cfg, seed=c["seed"]).items()},
+                                         strict=True)
+    sol = sol.to(DEV)
+    x, fx, y = (torch.from_numpy(g[f"{tag}.{k}"]).to(DEV) for k in ("x", "fx", "y"))
+    pred = sol(x, fx)
+    loss = TestLoss(size_average=False)(pred.reshape(2, -1), y.reshape(2, -1))
+    loss.backward()
+    assert rel_l2(pred, g[f"{tag}.pred.f64"]) < 1e-5
+    assert abs(loss.item() - float(g[f"{tag}.loss.f64"])) < 1e-5 * float(g[f"{tag}.loss.f64"])
+    for k, p in sol.transolver_model.named_parameters():
+        if k == "placeholder":
+            assert p.grad is None
+            continue
+        assert rel_l2(p.grad, g[f"{tag}.grad.f64.{k}"]) < _grad_tol(k), k
 
 
 def test_unrolled_lookahead_training_iteration_matches_oracle():
@@ -248,15 +279,10 @@ def test_bf16_compute_mode_full_ns_model():
     m = harness.build_model(cfg, synth.synth_state_dict(cfg, seed=51), DEV)
     pos, a, u = synth.ns_batch(1, seed=52)
     x, fx = torch.from_numpy(pos).to(DEV), torch.from_numpy(a).to(DEV)
-    lib = _lib.load()
-    prev_mode = lib.pa2d_get_gemm_mode()
-    lib.pa2d_set_gemm_mode(2)
-    try:
-        pred = m(x, fx=fx)
-        pred.square().sum().backward()
-        e = rel_l2(pred.reshape(-1), g["pred"])
-    finally:
-        lib.pa2d_set_gemm_mode(prev_mode)
+    m.set_engine("bf16")
+    pred = m(x, fx=fx)
+    pred.square().sum().backward()
+    e = rel_l2(pred.reshape(-1), g["pred"])
     assert 1e-5 < e < 3e-2, e          # really ran in reduced precision, and within the bf16 tolerance
     assert all(torch.isfinite(p.grad).all() for k, p in m.named_parameters() if p.grad is not None)
 
@@ -412,35 +438,30 @@ def test_c_abi_error_codes_on_device():
         ops.linear_fwd(torch.zeros(4, 4), torch.zeros(4, 4))
 
 
-def test_split_engine_full_ns_model_meets_fp32_tolerances():
-    """pa2d_set_gemm_mode(1): every conv GEMM (forward, data gradient, weight gradient) on the 6-term bf16-split
-    engine with pre-split activation planes — the full BASELINE configs[1] model must pass the G5 fixture with
-    the SAME fp32 tolerances as the exact engine."""
-    from transformerbasednavierstokesolver_amd import _lib
-    lib = _lib.load()
-    prev_mode = lib.pa2d_get_gemm_mode()
-    lib.pa2d_set_gemm_mode(1)
-    try:
-        test_g5_full_ns_config_forward_backward()
-    finally:
-        lib.pa2d_set_gemm_mode(prev_mode)
-
-
-def test_graphed_rollout_refuses_a_changed_gemm_engine():
-    """The weight-pack layout belongs to the GEMM engine that was active at capture: replaying (and refreshing the
-    packs) under another engine must fail loudly instead of feeding the captured kernels a foreign layout."""
-    from transformerbasednavierstokesolver_amd import synth, harness, _lib
-    cfg = dict(synth.NS_SMALL_CONFIG, n_layers=1)
-    m = harness.build_model(cfg, synth.synth_state_dict(cfg, seed=81), DEV).eval()
+def test_two_models_on_different_engines_coexist():
+    """The engine is a per-call argument (no process state): a model on the exact engine and one on the bf16-compute
+    engine interleave in one process — inside ONE weights_frozen scope, so their weight packs (different layouts)
+    must not cross — and each reproduces its own solo result bit for bit."""
+    from transformerbasednavierstokesolver_amd import synth, harness, ops
+    cfg = dict(synth.NS_SMALL_CONFIG, n_layers=2)
+    sd = synth.synth_state_dict(cfg, seed=81)
     pos, a, _ = synth.ns_batch(1, seed=82)
     x, fx = torch.from_numpy(pos).to(DEV), torch.from_numpy(a).to(DEV)
-    gr = harness.GraphedRollout(m, x, fx)
-    lib = _lib.load()
-    prev_mode = lib.pa2d_get_gemm_mode()
-    lib.pa2d_set_gemm_mode(2)
-    try:
-        with pytest.raises(RuntimeError, match="GEMM engine"):
-            gr.run(fx, 1)
-    finally:
-        lib.pa2d_set_gemm_mode(prev_mode)
-    assert gr.run(fx, 2).shape[-1] == 2
+    models = {e: harness.build_model(cfg, sd, DEV, engine=e).eval() for e in ("f32", "split", "bf16")}
+    with torch.no_grad():
+        solo = {e: m(x, fx=fx) for e, m in models.items()}
+        with ops.weights_frozen():
+            mixed = {}
+            for _ in range(2):                        # second round reuses the packs made in the first
+                for e, m in models.items():
+                    mixed[e] = m(x, fx=fx)
+    for e in models:
+        assert torch.equal(mixed[e], solo[e]), e
+    assert rel_l2(solo["split"], solo["f32"]) < 1e-5 and 1e-5 < rel_l2(solo["bf16"], solo["f32"]) < 3e-2
+    assert harness.model_engine(models["bf16"]) == ops.ENGINE_BF16
+    # a graphed rollout keeps ITS model's engine whatever other models run in between
+    gr = harness.GraphedRollout(models["split"], x, fx)
+    ref = harness.rollout(models["split"], x, fx, 2)
+    with torch.no_grad():
+        models["bf16"](x, fx=fx)
+    assert torch.equal(gr.run(fx, 2), ref)

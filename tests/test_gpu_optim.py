@@ -204,17 +204,11 @@ def test_time_folding_splits_into_groups_under_the_descriptor_limit(monkeypatch)
     sd = synth.synth_state_dict(cfg, seed=181)
     pos, a, u = synth.ns_batch(2, seed=182)
     x, fx, yy = (torch.from_numpy(t).to(DEV) for t in (pos, a, u))
-    m = harness.build_model(cfg, sd, DEV).train()
+    m = harness.build_model(cfg, sd, DEV, engine="f32").train()
     assert harness._fold_group(m, 2, 4096, 10) == 10
-    assert harness._fold_group(harness.build_model(synth.NS_CONFIG, None, "cpu"), 64, 4096, 10) == 7   # B=64, C=256
-    from transformerbasednavierstokesolver_amd import _lib
-    lib = _lib.load()
-    prev_mode = lib.pa2d_get_gemm_mode()
-    lib.pa2d_set_gemm_mode(1)                # 3-plane bf16 image of the 2C-wide gradient: 6 B per element
-    try:
-        assert harness._fold_group(harness.build_model(synth.NS_CONFIG, None, "cpu"), 64, 4096, 10) == 5
-    finally:
-        lib.pa2d_set_gemm_mode(prev_mode)
+    assert harness._fold_group(harness.build_model(synth.NS_CONFIG, None, "cpu", engine="f32"), 64, 4096, 10) == 7   # B=64, C=256
+    # 3-plane bf16 image of the 2C-wide gradient on the split engine: 6 B per element
+    assert harness._fold_group(harness.build_model(synth.NS_CONFIG, None, "cpu", engine="split"), 64, 4096, 10) == 5
     monkeypatch.setattr(harness, "FOLD_MAX_BYTES", 4 * 2 * 64 * (4 * 2 * 4096) + 100)
     assert harness._fold_group(m, 2, 4096, 10) == 4
     calls = []
@@ -227,3 +221,124 @@ def test_time_folding_splits_into_groups_under_the_descriptor_limit(monkeypatch)
     loss_s, full_s, pred_s = harness.train_iteration(m, x, fx, yy, loss_fn=lf)
     assert rel_l2(pred_f.detach(), pred_s.detach()) < 2e-6
     assert abs(float(loss_f.detach()) - float(loss_s.detach())) < 2e-6 * abs(float(loss_s.detach()))
+
+
+def test_fused_adamw_state_dict_round_trips_moments_and_step():
+    """save -> load into a fresh optimizer -> step == uninterrupted run, and == torch.optim.AdamW (whose state_dict
+    round-trips the moments and step count too)."""
+    from transformerbasednavierstokesolver_amd.optim import FusedAdamW
+    g = torch.Generator(device=DEV).manual_seed(9)
+    xs = [torch.randn(32, 37, device=DEV, generator=g) for _ in range(5)]
+
+    def run(m, o, batches):
+        for x in batches:
+            o.zero_grad()
+            m(x).square().sum().backward()
+            o.step()
+
+    a, b, c = _toy(), _toy(), _toy()
+    oa = FusedAdamW(a.parameters(), lr=3e-3, weight_decay=1e-2)
+    run(a, oa, xs)                                           # uninterrupted
+    ob = FusedAdamW(b.parameters(), lr=3e-3, weight_decay=1e-2)
+    run(b, ob, xs[:3])
+    saved = ob.state_dict()
+    assert int(saved["fused"]["steps"]) == 3 and float(saved["fused"]["exp_avg"].abs().sum()) > 0
+    b2 = _toy()
+    b2.load_state_dict(b.state_dict())
+    ob2 = FusedAdamW(b2.parameters(), lr=3e-3, weight_decay=1e-2)
+    ob2.load_state_dict(saved)
+    run(b2, ob2, xs[3:])
+    oc = torch.optim.AdamW(c.parameters(), lr=3e-3, weight_decay=1e-2)
+    run(c, oc, xs)
+    for (k, pa), (_, pb), (_, pc) in zip(a.named_parameters(), b2.named_parameters(), c.named_parameters()):
+        assert torch.equal(pa, pb), k                       # resume is exact
+        assert rel_l2(pa, pc) < 2e-6, k
+    assert torch.equal(a.unused, b2.unused)
+
+
+def test_first_step_bias_correction_matches_torch_double_arithmetic():
+    """step 1: 1 - beta^1 evaluated in double on the host.  lr = 1 makes the update (+-1 per element at step 1)
+    dominate the parameter, so an error in lr / bias1 shows up undiluted."""
+    from transformerbasednavierstokesolver_amd.optim import FusedAdamW
+    a, b = _toy(), _toy()
+    oa = torch.optim.AdamW(a.parameters(), lr=1.0, betas=(0.95, 0.999), weight_decay=0.0)
+    ob = FusedAdamW(b.parameters(), lr=1.0, betas=(0.95, 0.999), weight_decay=0.0)
+    x = torch.randn(16, 37, device=DEV, generator=torch.Generator(device=DEV).manual_seed(2))
+    for m, o in ((a, oa), (b, ob)):
+        o.zero_grad()
+        m(x).square().sum().backward()
+        o.step()
+    for (k, pa), (_, pb) in zip(a.named_parameters(), b.named_parameters()):
+        if k == "unused":
+            continue
+        assert rel_l2(pb, pa) < 5e-7, k
+
+
+def test_rel_l2_backward_is_finite_for_zero_weight_and_exact_prediction():
+    """reduction=False with a zero per-sample weight, and a sample with pred == y (dnorm = 0): the reference's
+    torch.norm backward gives 0 there; the fused kernel must not put inf/NaN into the gradient bucket."""
+    from transformerbasednavierstokesolver_amd.utils.testloss import TestLoss, FusedTestLoss
+    g = torch.Generator(device=DEV).manual_seed(3)
+    y = torch.randn(4, 300, device=DEV, generator=g)
+    pred = torch.randn(4, 300, device=DEV, generator=g)
+    pred[2] = y[2]                                           # exact prediction
+    w = torch.tensor([1.0, 0.0, 2.0, 0.5], device=DEV)       # masked sample
+    p1 = pred.clone().requires_grad_(True)
+    p2 = pred.clone().requires_grad_(True)
+    (FusedTestLoss(reduction=False)(p1, y) * w).sum().backward()
+    (TestLoss(reduction=False)(p2, y) * w).sum().backward()
+    assert torch.isfinite(p1.grad).all()
+    assert float(p1.grad[1].abs().max()) == 0.0 and float(p1.grad[2].abs().max()) == 0.0
+    assert torch.isfinite(p2.grad).all() and rel_l2(p1.grad, p2.grad) < 5e-6
+
+
+def test_rollout_graph_captured_before_the_optimizer_refuses_to_replay_stale_parameters():
+    """FusedAdamW re-seats every parameter into its flat buffer at construction.  A GraphedRollout captured BEFORE
+    that holds the old pointers: run() must raise instead of replaying stale weights; captured AFTER, it follows
+    the optimizer's updates."""
+    from transformerbasednavierstokesolver_amd import synth, harness
+    from transformerbasednavierstokesolver_amd.optim import FusedAdamW
+    from transformerbasednavierstokesolver_amd.utils.testloss import FusedTestLoss
+    cfg = dict(synth.NS_SMALL_CONFIG, n_layers=2)
+    m = harness.build_model(cfg, synth.synth_state_dict(cfg, seed=191), DEV)
+    pos, a, u = synth.ns_batch(2, seed=192)
+    x, fx, yy = (torch.from_numpy(t).to(DEV) for t in (pos, a, u[..., :2]))
+    early = harness.GraphedRollout(m.eval(), x, fx)
+    early.run(fx, 1)
+    opt = FusedAdamW(m.parameters(), lr=1e-2, weight_decay=1e-5)
+    with pytest.raises(RuntimeError, match="parameter storage moved"):
+        early.run(fx, 1)
+    late = harness.GraphedRollout(m.eval(), x, fx)
+    before = late.run(fx, 2)
+    harness.train_step(m.train(), opt, None, x, fx, yy, grad_sync=opt.sync, loss_fn=FusedTestLoss(size_average=False))
+    after = late.run(fx, 2)
+    assert torch.equal(after, harness.rollout(m.eval(), x, fx, 2))      # the graph sees the updated weights
+    assert not torch.equal(after, before)
+
+
+def test_parameter_first_used_after_the_optimizer_was_built_is_stepped():
+    """`placeholder` gets no gradient while fx is given (…_2D.py:205-210) and must stay bit-identical (no weight
+    decay); once a call with fx=None uses it, it is reduced and stepped like torch.optim.AdamW would."""
+    from transformerbasednavierstokesolver_amd import synth, harness
+    from transformerbasednavierstokesolver_amd.optim import FusedAdamW
+    cfg = dict(synth.TINY_CONFIG, fun_dim=0, unified_pos=0)
+    sd = synth.synth_state_dict(cfg, seed=201)
+    N = cfg["H"] * cfg["W"]
+    rng = np.random.default_rng(202)
+    x = torch.from_numpy(rng.standard_normal((2, N, 2)).astype(np.float32)).to(DEV)
+    m = harness.build_model(cfg, sd, DEV).train()
+    opt = FusedAdamW(m.parameters(), lr=1e-2, weight_decay=1e-1)
+    p0 = m.placeholder.detach().clone()
+    # step 1: only the head parameters get gradients (loss on a detached trunk): placeholder untouched
+    opt.zero_grad()
+    m.blocks[-1].mlp2.weight.square().sum().backward()
+    opt.sync()
+    opt.step()
+    assert torch.equal(m.placeholder.detach(), p0) and m.placeholder.grad is None
+    # step 2: fx=None -> placeholder is used
+    opt.zero_grad()
+    m(x, None).square().sum().backward()
+    opt.sync()
+    opt.step()
+    assert not torch.equal(m.placeholder.detach(), p0)
+    assert m.placeholder.grad is not None and m.placeholder.grad.data_ptr() == opt.sync.views[opt.sync.index_of(m.placeholder)].data_ptr()

@@ -150,7 +150,8 @@ def test_c_abi_exports_every_declared_symbol_with_matching_arity():
     assert lib.pa2d_version().startswith(b"pa2d")
     # pure host-side helpers may be called without a GPU
     assert lib.pa2d_slice_nchunk(32, 4096, 8) == 4 and lib.pa2d_slice_nchunk(1, 4096, 8) == 16
-    assert lib.pa2d_gemm_bwd_weight_workspace(131072, 256, 256) > 0
+    assert lib.pa2d_gemm_bwd_weight_workspace(131072, 256, 256, 0) > 0
+    assert lib.pa2d_default_engine() in (0, 1, 2)
 
 
 def test_missing_library_fails_loudly(monkeypatch):
@@ -166,8 +167,10 @@ def test_size_helpers_accept_empty_problems():
     reductions and skip the launches)."""
     from transformerbasednavierstokesolver_amd import _lib
     lib = _lib.load()
-    assert lib.pa2d_gemm_bwd_weight_workspace(0, 64, 64) > 0
-    assert lib.pa2d_conv3x3x2_workspace(0, 64, 64, 64) >= lib.pa2d_conv3x3x2_pack_bytes(64)
+    for engine in (0, 1, 2):
+        assert lib.pa2d_gemm_bwd_weight_workspace(0, 64, 64, engine) > 0
+        assert lib.pa2d_conv3x3x2_workspace(0, 64, 64, 64, engine) >= lib.pa2d_conv3x3x2_pack_bytes(64)
+        assert lib.pa2d_conv3x3x2_fwd_workspace(0, 64, 64, 64, engine) >= lib.pa2d_conv3x3x2_pack_bytes(64)
     assert lib.pa2d_layernorm_bwd_workspace(0, 64) >= 0 and lib.pa2d_head_bwd_workspace(0, 64, 1) >= 0
     assert lib.pa2d_slice_bwd_workspace(0, 4096, 8, 8, 32) >= 0 and lib.pa2d_sumsq_workspace(0) >= 0
     assert lib.pa2d_slice_nchunk(0, 4096, 8) >= 1 and lib.pa2d_slice_nchunk(1, 0, 8) == 1

@@ -134,3 +134,26 @@ def test_g6_irregular_mesh_family(tag):
     assert rel_l2(_sample(pred), g[f"{tag}.pred.sample"]) < 1e-12
     for k in sd:
         assert abs(float(sdo[k].grad.norm()) - float(g[f"{tag}.grad.norm.{k}"])) < 1e-9 * float(g[f"{tag}.grad.norm.{k}"]) + 1e-300, k
+
+
+G7_CASES = {"s1n3": dict(fun_dim=4, out_dim=1, step=1, n=3, seed=71), "s2n2": dict(fun_dim=6, out_dim=2, step=2, n=2, seed=73)}
+
+
+@pytest.mark.parametrize("tag", list(G7_CASES))
+@pytest.mark.parametrize("dt,dtype,tol", [("f64", torch.float64, 1e-12), ("f32", torch.float32, 2e-5)])
+def test_g7_sol_wrapper_bptt(tag, dt, dtype, tol):
+    """oracle.sol_forward vs the fixture the reference's SOL_Transolver_Structured_Mesh_2D produced
+    (model/SOL_Transolver_Structured_Mesh_2D.py:47-52): n chained calls, loss on the last prediction, BPTT."""
+    g = np.load(os.path.join(GOLDEN, "G7_sol_wrapper.npz"))
+    c = G7_CASES[tag]
+    cfg = dict(synth.TINY_CONFIG, fun_dim=c["fun_dim"], out_dim=c["out_dim"])
+    sd = orc.to_torch(synth.synth_state_dict(cfg, seed=c["seed"]), dtype, requires_grad=True)
+    x, fx, y = (torch.from_numpy(g[f"{tag}.{k}"]).to(dtype) for k in ("x", "fx", "y"))
+    pred = orc.sol_forward(sd, x, fx, cfg, c["n"], step=c["step"])
+    assert rel_l2(pred, g[f"{tag}.pred.{dt}"]) < tol
+    loss = orc.rel_l2(pred.reshape(2, -1), y.reshape(2, -1))
+    assert abs(loss.item() - float(g[f"{tag}.loss.{dt}"])) < 50 * tol * abs(float(g[f"{tag}.loss.{dt}"]))
+    loss.backward()
+    for k in sd:
+        if k != "placeholder":
+            assert rel_l2(sd[k].grad, g[f"{tag}.grad.{dt}.{k}"]) < 50 * tol, k

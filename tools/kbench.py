@@ -31,13 +31,16 @@ def main():
     ap.add_argument("--B", type=int, default=32)
     ap.add_argument("--C", type=int, default=256)
     ap.add_argument("--M", type=int, default=64)
-    ap.add_argument("--gemm-mode", type=int, default=0, help="0 f32 MFMA, 1 6-term bf16 split (conv), 2 bf16 compute")
+    ap.add_argument("--engine", default=None, help="f32 | split | bf16 (default: PA2D_GEMM / split)")
+    ap.add_argument("--H", type=int, default=64)
+    ap.add_argument("--W", type=int, default=64)
+    ap.add_argument("--heads", type=int, default=8)
     args = ap.parse_args()
-    from transformerbasednavierstokesolver_amd import _lib
-    _lib.load().pa2d_set_gemm_mode(args.gemm_mode)
+    E = ops.resolve_engine(args.engine)
+    print(f"engine {E}  B={args.B} H={args.H} W={args.W} C={args.C} M={args.M}", flush=True)
     only = set(filter(None, args.only.split(",")))
     dev = "cuda:0"
-    B, H, W, C, heads, M = args.B, 64, 64, args.C, 8, args.M
+    B, H, W, C, heads, M = args.B, args.H, args.W, args.C, args.heads, args.M
     N, D = H * W, C // heads
     R = B * N
     g = torch.Generator(device=dev).manual_seed(0)
@@ -57,16 +60,16 @@ def main():
     conv_flops = 2.0 * R * 9 * C * 2 * C
     lin_flops = 2.0 * R * C * C
     tests = {}
-    tests["conv_fwd"] = (lambda: ops.conv3x3x2_fwd(xn, wx, bx, wf, bf, H, W), conv_flops, "TF")
-    tests["conv_bwd"] = (lambda: ops.conv3x3x2_bwd(dout2, xn, wx, wf, H, W), 2 * conv_flops, "TF")
-    tests["conv_bwd_wonly"] = (lambda: ops.conv3x3x2_bwd(dout2, xn, wx, wf, H, W, need_dx=False), conv_flops, "TF")
-    tests["linear_fwd"] = (lambda: ops.linear_fwd(x2d, w, bias, act="gelu", want_pre=True), lin_flops, "TF")   # MLP1
-    tests["linear_plain"] = (lambda: ops.linear_fwd(x2d, w), lin_flops, "TF")
-    tests["linear_bias_res"] = (lambda: ops.linear_fwd(x2d, w, bias, res=res), lin_flops, "TF")
-    tests["linear_gelu"] = (lambda: ops.linear_fwd(x2d, w, bias, act="gelu"), lin_flops, "TF")
-    tests["linear_bwd_plain"] = (lambda: ops.linear_bwd_data(dy2d, w), lin_flops, "TF")
-    tests["linear_bwd_data"] = (lambda: ops.linear_bwd_data(dy2d, w, pre=x2d, act="gelu"), lin_flops, "TF")
-    tests["linear_bwd_weight"] = (lambda: ops.linear_bwd_weight(dy2d, x2d), lin_flops, "TF")
+    tests["conv_fwd"] = (lambda: ops.conv3x3x2_fwd(xn, wx, bx, wf, bf, H, W, engine=E), conv_flops, "TF")
+    tests["conv_bwd"] = (lambda: ops.conv3x3x2_bwd(dout2, xn, wx, wf, H, W, engine=E), 2 * conv_flops, "TF")
+    tests["conv_bwd_wonly"] = (lambda: ops.conv3x3x2_bwd(dout2, xn, wx, wf, H, W, need_dx=False, engine=E), conv_flops, "TF")
+    tests["linear_fwd"] = (lambda: ops.linear_fwd(x2d, w, bias, act="gelu", want_pre=True, engine=E), lin_flops, "TF")   # MLP1
+    tests["linear_plain"] = (lambda: ops.linear_fwd(x2d, w, engine=E), lin_flops, "TF")
+    tests["linear_bias_res"] = (lambda: ops.linear_fwd(x2d, w, bias, res=res, engine=E), lin_flops, "TF")
+    tests["linear_gelu"] = (lambda: ops.linear_fwd(x2d, w, bias, act="gelu", engine=E), lin_flops, "TF")
+    tests["linear_bwd_plain"] = (lambda: ops.linear_bwd_data(dy2d, w, engine=E), lin_flops, "TF")
+    tests["linear_bwd_data"] = (lambda: ops.linear_bwd_data(dy2d, w, pre=x2d, act="gelu", engine=E), lin_flops, "TF")
+    tests["linear_bwd_weight"] = (lambda: ops.linear_bwd_weight(dy2d, x2d, engine=E), lin_flops, "TF")
     y, mean, rstd = ops.layernorm_fwd(x2d, gamma, beta)
     tests["ln_fwd"] = (lambda: ops.layernorm_fwd(x2d, gamma, beta), 2.0 * R * C * 4, "GB")
     tests["ln_bwd"] = (lambda: ops.layernorm_bwd(dy2d, x2d, mean, rstd, gamma, res), 4.0 * R * C * 4, "GB")

@@ -21,38 +21,38 @@ _st = C.c_void_p     # hipStream_t
 # name -> (restype, argtypes); mirrors include/pa2d.h one to one
 SIGNATURES = {
     "pa2d_version": (C.c_char_p, []),
-    "pa2d_set_gemm_mode": (None, [_i]),
-    "pa2d_get_gemm_mode": (_i, []),
+    "pa2d_default_engine": (_i, []),
     "pa2d_layernorm_fwd": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, C.c_float, _st]),
     "pa2d_layernorm_bwd_workspace": (_sz, [_i, _i]),
-    "pa2d_layernorm_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _sz, _i, _i, _st]),
-    "pa2d_gemm_bias_act_fwd": (_i, [_f, _ll, _f, _ll, _f, _f, _ll, _f, _ll, _f, _ll, _i, _i, _i, _i, _st]),
-    "pa2d_gemm_bwd_data": (_i, [_f, _ll, _f, _ll, _f, _ll, _i, _f, _ll, _f, _i, _i, _i, _st]),
-    "pa2d_gemm_bwd_weight_workspace": (_sz, [_i, _i, _i]),
-    "pa2d_gemm_bwd_weight": (_i, [_f, _ll, _f, _ll, _f, _f, _f, _sz, _i, _i, _i, _st]),
-    "pa2d_conv3x3x2_workspace": (_sz, [_i, _i, _i, _i]),
-    "pa2d_conv3x3x2_fwd_workspace": (_sz, [_i, _i, _i, _i]),
+    "pa2d_layernorm_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _st]),
+    "pa2d_gemm_bias_act_fwd": (_i, [_f, _ll, _f, _ll, _f, _f, _ll, _f, _ll, _f, _ll, _i, _i, _i, _i, _i, _st]),
+    "pa2d_gemm_bwd_data": (_i, [_f, _ll, _f, _ll, _f, _ll, _i, _f, _ll, _f, _i, _i, _i, _i, _st]),
+    "pa2d_gemm_bwd_weight_workspace": (_sz, [_i, _i, _i, _i]),
+    "pa2d_gemm_bwd_weight": (_i, [_f, _ll, _f, _ll, _f, _f, _f, _sz, _i, _i, _i, _i, _i, _st]),
+    "pa2d_conv3x3x2_workspace": (_sz, [_i, _i, _i, _i, _i]),
+    "pa2d_conv3x3x2_fwd_workspace": (_sz, [_i, _i, _i, _i, _i]),
     "pa2d_conv3x3x2_pack_bytes": (_sz, [_i]),
-    "pa2d_conv3x3x2_pack": (_i, [_f, _f, _f, _sz, _i, _i, _i, _i, _i, _st]),
-    "pa2d_conv3x3x2_fwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _i, _st, _st, _st]),
-    "pa2d_conv3x3x2_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _i, _st, _st, _st]),
+    "pa2d_conv3x3x2_pack": (_i, [_f, _f, _f, _sz, _i, _i, _i, _i, _i, _i, _st]),
+    "pa2d_conv3x3x2_fwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _i, _i, _st, _st, _st]),
+    "pa2d_conv3x3x2_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _i, _i, _i, _st, _st,
+                                _st]),
     "pa2d_slice_nchunk": (_i, [_i, _i, _i]),
-    "pa2d_slice_scatter": (_i, [_f, _ll, _f, _ll, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _st]),
+    "pa2d_slice_scatter": (_i, [_f, _ll, _f, _ll, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _st, _st, _st]),
     "pa2d_token_attn_lds_bytes": (_sz, [_i, _i, _i]),
     "pa2d_token_attn_fwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _st]),
     "pa2d_token_attn_bwd_workspace": (_sz, [_i, _i]),
-    "pa2d_token_attn_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _i, _st]),
-    "pa2d_deslice_fwd": (_i, [_f, _ll, _f, _f, _f, _f, _f, _ll, _i, _i, _i, _i, _i, _i, _st]),
+    "pa2d_token_attn_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _i, _i, _st]),
+    "pa2d_deslice_fwd": (_i, [_f, _ll, _f, _f, _f, _f, _f, _ll, _i, _i, _i, _i, _i, _i, _st, _st, _st]),
     "pa2d_slice_bwd_workspace": (_sz, [_i, _i, _i, _i, _i]),
     "pa2d_slice_bwd_points": (_i, [_f, _ll, _f, _ll, _f, _ll, _f, _f, _f, _f, _f, _f, _f, _ll, _f, _ll, _f, _f, _f,
-                                   _f, _sz, _i, _i, _i, _i, _i, _i, _st]),
+                                   _f, _sz, _i, _i, _i, _i, _i, _i, _i, _st, _st, _st]),
     "pa2d_head_fwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _st]),
     "pa2d_head_bwd_workspace": (_sz, [_i, _i, _i]),
-    "pa2d_head_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _st]),
+    "pa2d_head_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _i, _st]),
     "pa2d_act_bwd": (_i, [_f, _f, _f, _ll, _i, _st]),
     "pa2d_sumsq_workspace": (_sz, [_ll]),
     "pa2d_sumsq": (_i, [_f, _ll, _f, _f, _sz, _st]),
-    "pa2d_adamw_step": (_i, [_f, _f, _f, _f, _ll, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _i, _f,
+    "pa2d_adamw_step": (_i, [_f, _f, _f, _f, _ll, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, _i, _f,
                              C.c_float, _st]),
     "pa2d_rel_l2_fwd": (_i, [_f, _f, _f, _f, _f, _i, _ll, _st]),
     "pa2d_rel_l2_bwd": (_i, [_f, _f, _f, _f, _f, _f, _i, _ll, _st]),

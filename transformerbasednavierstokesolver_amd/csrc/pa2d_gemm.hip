@@ -2,16 +2,11 @@
 // pa2d_gemm_kc.hip (exact fp32), pa2d_gemm_split.hip (bf16 engines) and pa2d_gemm_mc.hip (weight gradients).
 #include "pa2d_gemm_common.h"
 
-// engine selection: PA2D_GEMM=f32 (v_mfma_f32_32x32x2_f32, default) | split (6-term bf16 split, fp32
-// accuracy, conv GEMMs only) | bf16 (1-term bf16 compute for every GEMM, fp32 accumulate/storage)
-static int g_gemm_mode = -1;   // process-wide knob (pa2d_set_gemm_mode / env PA2D_GEMM)
-int gemm_mode() {
-    if (g_gemm_mode < 0) {
-        const char* e = getenv("PA2D_GEMM");
-        g_gemm_mode = !e ? 0 : (e[0] == 's' ? 1 : (e[0] == 'b' ? 2 : 0));
-    }
-    return g_gemm_mode;
-}
+// Engines (explicit `engine` argument of every dense entry point; the library keeps NO engine state, so two
+// models in one process can use different engines): 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = 6-term bf16
+// split at fp32 accuracy (conv GEMMs; other GEMMs stay exact), 2 = bf16 compute for every GEMM (fp32 accumulate
+// and storage).  pa2d_default_engine() only reads the environment (PA2D_GEMM=f32|split|bf16), default = split.
+static bool engine_ok(int e) { return e >= 0 && e <= 2; }
 // (the split engine serves the conv implicit GEMMs only: the short-K linears gain nothing from it)
 // K-step: 32 (half the barriers of 16, full 128-byte row segments; 3-4 % faster on the conv, ~10 % on the small tiles)
 // whenever the layout allows it: plain GEMMs always, the conv when Cin % 32 == 0; otherwise 16.
@@ -33,8 +28,8 @@ KCTile kc_tile(int M, int N, bool im2col, int Cin) {
     if (t12864 >= 384 || M <= 64) return {128, 64, bk};
     return {64, 64, bk};
 }
-bool use_split(int N, bool im2col, int Cin) {
-    const int m = gemm_mode();
+bool use_split(int engine, int N, bool im2col, int Cin) {
+    const int m = engine;
     if (m == 1) return im2col && N > 64 && (Cin % 32) == 0;
     if (m == 2) return N > 64 && (!im2col || (Cin % 32) == 0);
     return false;
@@ -42,6 +37,7 @@ bool use_split(int N, bool im2col, int Cin) {
 
 static int launch_kc(const KCParams& p_in, bool im2col, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
     KCParams p = p_in;
+    if (!engine_ok(p.engine)) return PA2D_ERR_ARG;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return PA2D_OK;
     if (!p.bias2) p.bias_split = 0x7fffffff;
     {   // 32-bit byte offsets inside the buffer descriptors
@@ -61,7 +57,7 @@ static int launch_kc(const KCParams& p_in, bool im2col, hipStream_t st, hipEvent
     if (im2col && (p.epi != 0 || p.res)) return PA2D_ERR_ARG;      // conv kernels carry the bias-only epilogue
     if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return PA2D_ERR_ARG;
     int rc;
-    if (use_split(p.N, im2col, p.Cin)) rc = launch_kc_split(p, im2col, st);
+    if (use_split(p.engine, p.N, im2col, p.Cin)) rc = launch_kc_split(p, im2col, st);
     else rc = launch_kc_f32(p, im2col, kc_tile(p.M, p.N, im2col, p.Cin), st);
     if (rc) return rc;
     if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return PA2D_ERR_ARG;
@@ -117,14 +113,19 @@ static int launch_repack(const float* w0, const float* w1, float* dst, int mode,
 // C ABI (declared in include/pa2d.h)
 extern "C" {
 
-// 0 = exact fp32 MFMA engine (default), 1 = experimental 6-term bf16-split engine for the conv GEMMs
-void pa2d_set_gemm_mode(int mode) { g_gemm_mode = (mode == 1 || mode == 2) ? mode : 0; }
-int pa2d_get_gemm_mode(void) { return gemm_mode(); }
+// The engine a caller should use when it has no preference: env PA2D_GEMM=f32|split|bf16, else the fp32-accurate
+// split engine.  A pure function of the environment — nothing in the library reads it implicitly.
+int pa2d_default_engine(void) {
+    const char* e = getenv("PA2D_GEMM");
+    if (!e || !e[0]) return 1;
+    return e[0] == 'f' ? 0 : (e[0] == 'b' ? 2 : 1);
+}
 
 int pa2d_gemm_bias_act_fwd(const float* x, long long ldx, const float* w, long long ldw, const float* bias,
                            const float* res, long long ldres, float* y, long long ldy, float* pre, long long ldpre,
-                           int M, int N, int K, int act, hipStream_t st) {
+                           int M, int N, int K, int act, int engine, hipStream_t st) {
     KCParams p = {};
+    p.engine = engine;
     p.A = x; p.lda = ldx; p.B = w; p.ldb = ldw; p.C = y; p.ldc = ldy; p.bias = bias; p.res = res; p.ldres = ldres;
     p.aux = pre; p.ldaux = ldpre; p.M = M; p.N = N; p.K = K; p.act = act;
     p.epi = (act != ACT_NONE ? EPI_ACT : 0) | (pre ? EPI_STORE_PRE : 0);
@@ -135,76 +136,85 @@ int pa2d_gemm_bias_act_fwd(const float* x, long long ldx, const float* w, long l
 // wt_ws: K*N floats of scratch for the transposed weight.
 int pa2d_gemm_bwd_data(const float* dy, long long lddy, const float* w, long long ldw, const float* pre,
                        long long ldpre, int act, float* dx, long long lddx, float* wt_ws, int M, int N, int K,
-                       hipStream_t st) {
+                       int engine, hipStream_t st) {
     if (ldw != K) return PA2D_ERR_ARG;
     if (N & 3) return PA2D_ERR_ARG;
     if (M <= 0) return PA2D_OK;
     int rc = launch_repack(w, nullptr, wt_ws, 0, N, K, 0, 0, st);
     if (rc) return rc;
     KCParams p = {};
+    p.engine = engine;
     p.A = dy; p.lda = lddy; p.B = wt_ws; p.ldb = N; p.C = dx; p.ldc = lddx; p.M = M; p.N = K; p.K = N;
     p.aux = const_cast<float*>(pre); p.ldaux = ldpre; p.act = act;
     p.epi = (pre && act != ACT_NONE) ? EPI_MUL_DACT : 0;
     return launch_kc(p, false, st);
 }
 
-size_t pa2d_gemm_bwd_weight_workspace(int M, int N, int K) {
+size_t pa2d_gemm_bwd_weight_workspace(int M, int N, int K, int engine) {
+    (void)engine;
     const MCPlan pl = plan_mc(N, K, M);
     size_t a = pl.slab_floats, b = (size_t)colsum_blocks(M) * N;
     return (a > b ? a : b) * sizeof(float);
 }
 
-// dw[N,K] = dy[M,N]^T . x[M,K] ; db[N] = column sums of dy (db may be NULL)
+// dw[N,K] (+)= dy[M,N]^T . x[M,K] ; db[N] (+)= column sums of dy (db may be NULL).  accumulate != 0: add to what dw / db
+// hold (gradient accumulation straight into the caller's bucket, done inside the slab-reduce pass).
 int pa2d_gemm_bwd_weight(const float* dy, long long lddy, const float* x, long long ldx, float* dw, float* db,
-                         void* ws, size_t ws_bytes, int M, int N, int K, hipStream_t st) {
-    if (M <= 0) { const int rz = pa2d_zero(dw, sizeof(float) * N * K, st); return rz ? rz : pa2d_zero(db, sizeof(float) * N, st); }
-    if (ws_bytes < pa2d_gemm_bwd_weight_workspace(M, N, K)) return PA2D_ERR_WORKSPACE;
+                         void* ws, size_t ws_bytes, int M, int N, int K, int accumulate, int engine, hipStream_t st) {
+    if (!engine_ok(engine)) return PA2D_ERR_ARG;
+    if (M <= 0) {
+        if (accumulate) return PA2D_OK;
+        const int rz = pa2d_zero(dw, sizeof(float) * N * K, st);
+        return rz ? rz : pa2d_zero(db, sizeof(float) * N, st);
+    }
+    if (ws_bytes < pa2d_gemm_bwd_weight_workspace(M, N, K, engine)) return PA2D_ERR_WORKSPACE;
     const MCPlan pl = plan_mc(N, K, M);
-    int rc = launch_mc(dy, lddy, N, x, ldx, K, M, false, 0, 0, 0, (float*)ws, pl, st);
+    int rc = launch_mc(dy, lddy, N, x, ldx, K, M, false, 0, 0, 0, (float*)ws, pl, engine, st);
     if (rc) return rc;
-    rc = launch_reduce((const float*)ws, pl.splits, (long long)N * K, dw, nullptr, 0, 0, 0, st);
+    rc = launch_reduce((const float*)ws, pl.splits, (long long)N * K, dw, nullptr, 0, 0, 0, st, accumulate);
     if (rc) return rc;
-    if (db) rc = launch_colsum(dy, lddy, M, N, db, (float*)ws, st);
+    if (db) rc = launch_colsum(dy, lddy, M, N, db, (float*)ws, st, nullptr, 0, accumulate);
     return rc;
 }
 
 // bf16 engines: bytes of the pre-split activation planes of a [rows, Cin] operand (0 when the engine selected for
 // this GEMM reads fp32 operands)
-static size_t conv_planes_bytes(int M, int N, int Cin) {
-    if (!use_split(N, true, Cin)) return 0;
-    return (planes_bytes(M, Cin, gemm_mode() == 2 ? 1 : 3) + 255) & ~(size_t)255;
+static size_t conv_planes_bytes(int engine, int M, int N, int Cin) {
+    if (!use_split(engine, N, true, Cin)) return 0;
+    return (planes_bytes(M, Cin, engine == 2 ? 1 : 3) + 255) & ~(size_t)255;
 }
 
 // bf16 engines: the weight gradient also runs from pre-split planes (of dOut and of X) when the tile shapes allow
-static bool conv_dw_from_planes(int M, int C) {
-    return conv_planes_bytes(M, C, 2 * C) != 0 && mc_planes_supported(C, C) && plan_mc(2 * C, 9 * C, M).big;
+static bool conv_dw_from_planes(int engine, int M, int C) {
+    return conv_planes_bytes(engine, M, C, 2 * C) != 0 && mc_planes_supported(C, C) && plan_mc(2 * C, 9 * C, M).big;
 }
-static size_t conv_xplanes_bytes(int M, int C) {
-    return conv_dw_from_planes(M, C) ? ((planes_bytes(M, C, gemm_mode() == 2 ? 1 : 3) + 255) & ~(size_t)255) : 0;
+static size_t conv_xplanes_bytes(int engine, int M, int C) {
+    return conv_dw_from_planes(engine, M, C) ? ((planes_bytes(M, C, engine == 2 ? 1 : 3) + 255) & ~(size_t)255) : 0;
 }
 
 // backward workspace: [weight pack | slabs or column-sum partials | dOut planes | X planes]  (planes: bf16 engines)
-size_t pa2d_conv3x3x2_workspace(int B, int H, int W, int C) {
+size_t pa2d_conv3x3x2_workspace(int B, int H, int W, int C, int engine) {
     const size_t pack = (size_t)3 * C * 9 * C;      // fp32 pack (2C*9C floats) or 3 bf16 planes (1.5x)
     const MCPlan pl = plan_mc(2 * C, 9 * C, B * H * W);
     size_t sl = pl.slab_floats, cs = (size_t)colsum_blocks(B * H * W) * 2 * C;
-    return (pack + (sl > cs ? sl : cs)) * sizeof(float) + conv_planes_bytes(B * H * W, C, 2 * C) +
-           conv_xplanes_bytes(B * H * W, C);
+    return (pack + (sl > cs ? sl : cs)) * sizeof(float) + conv_planes_bytes(engine, B * H * W, C, 2 * C) +
+           conv_xplanes_bytes(engine, B * H * W, C);
 }
 
 // forward workspace: [weight pack (unused if prepacked) | activation planes (bf16 engines)]
-size_t pa2d_conv3x3x2_fwd_workspace(int B, int H, int W, int C) {
-    return (size_t)3 * C * 9 * C * sizeof(float) + conv_planes_bytes(B * H * W, 2 * C, C);
+size_t pa2d_conv3x3x2_fwd_workspace(int B, int H, int W, int C, int engine) {
+    return (size_t)3 * C * 9 * C * sizeof(float) + conv_planes_bytes(engine, B * H * W, 2 * C, C);
 }
 
 // Packed conv weights in the layout the engine selected for these dims wants (channel chunk = K-step of the
 // tile, fp32 or bf16 planes by GEMM mode).  direction 0: forward pack ([2C][9C]); 1: data-gradient pack
 // ([C][9*2C], taps flipped).  pack: pa2d_conv3x3x2_pack_bytes(C) bytes.  A pack stays valid while the weights,
 // the dims and the GEMM mode do not change.
-static int conv_pack(const float* wx, const float* wf, float* pack, int M, int C, int direction, hipStream_t st) {
+static int conv_pack(const float* wx, const float* wf, float* pack, int M, int C, int direction, int engine,
+                     hipStream_t st) {
     const int N = direction ? C : 2 * C, Cin = direction ? 2 * C : C;
-    if (use_split(N, true, Cin)) {
-        return launch_repack_split(wx, wf, pack, direction, gemm_mode() == 2 ? 1 : 3, C, C, st);
+    if (use_split(engine, N, true, Cin)) {
+        return launch_repack_split(wx, wf, pack, direction, engine == 2 ? 1 : 3, C, C, st);
     }
     return launch_repack(wx, wf, pack, direction ? 2 : 1, 0, kc_tile(M, N, true, Cin).bk, C, C, st);
 }
@@ -212,9 +222,10 @@ static int conv_pack(const float* wx, const float* wf, float* pack, int M, int C
 size_t pa2d_conv3x3x2_pack_bytes(int C) { return (size_t)3 * C * 9 * C * sizeof(float); }
 
 int pa2d_conv3x3x2_pack(const float* wx, const float* wf, void* pack, size_t pack_bytes, int B, int H, int W, int C,
-                        int direction, hipStream_t st) {
+                        int direction, int engine, hipStream_t st) {
+    if (!engine_ok(engine)) return PA2D_ERR_ARG;
     if (pack_bytes < pa2d_conv3x3x2_pack_bytes(C)) return PA2D_ERR_WORKSPACE;
-    return conv_pack(wx, wf, (float*)pack, B * H * W, C, direction ? 1 : 0, st);
+    return conv_pack(wx, wf, (float*)pack, B * H * W, C, direction ? 1 : 0, engine, st);
 }
 
 // out[B*H*W, 2C] = [conv3x3(xn, wx) + bx | conv3x3(xn, wf) + bf]   (zero padding 1, NHWC)
@@ -223,22 +234,24 @@ int pa2d_conv3x3x2_pack(const float* wx, const float* wf, void* pack, size_t pac
 // pa2d_conv3x3x2_pack(direction 0) for the same B, H, W, C.
 int pa2d_conv3x3x2_fwd(const float* xn, const float* wx, const float* bx, const float* wf, const float* bf,
                        float* out, const void* prepacked, void* ws, size_t ws_bytes, int B, int H, int W, int C,
-                       hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
+                       int engine, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    if (!engine_ok(engine)) return PA2D_ERR_ARG;
     if (B <= 0) return PA2D_OK;
-    if (ws_bytes < pa2d_conv3x3x2_fwd_workspace(B, H, W, C)) return PA2D_ERR_WORKSPACE;
+    if (ws_bytes < pa2d_conv3x3x2_fwd_workspace(B, H, W, C, engine)) return PA2D_ERR_WORKSPACE;
     const float* pack = (const float*)prepacked;
     if (!pack) {
-        const int rc = conv_pack(wx, wf, (float*)ws, B * H * W, C, 0, st);
+        const int rc = conv_pack(wx, wf, (float*)ws, B * H * W, C, 0, engine, st);
         if (rc) return rc;
         pack = (const float*)ws;
     }
-    const size_t apl = conv_planes_bytes(B * H * W, 2 * C, C);
+    const size_t apl = conv_planes_bytes(engine, B * H * W, 2 * C, C);
     void* const planes = (char*)ws + pa2d_conv3x3x2_pack_bytes(C);
     if (apl) {
-        const int rc = launch_split_planes(xn, C, planes, (long long)B * H * W, C, gemm_mode() == 2 ? 1 : 3, st);
+        const int rc = launch_split_planes(xn, C, planes, (long long)B * H * W, C, engine == 2 ? 1 : 3, st);
         if (rc) return rc;
     }
     KCParams p = {};
+    p.engine = engine;
     p.A = apl ? (const float*)planes : xn; p.apre = apl ? 1 : 0;
     p.lda = C; p.B = pack; p.ldb = 9 * C; p.C = out; p.ldc = 2 * C;
     p.bias = bx; p.bias2 = bf; p.bias_split = C;
@@ -246,24 +259,27 @@ int pa2d_conv3x3x2_fwd(const float* xn, const float* wx, const float* bx, const 
     return launch_kc(p, true, st, ev_start, ev_stop);
 }
 
-// dxn[B*N, C] (+= nothing; plain store), dwx/dwf [C,C,3,3], dbx/dbf [C]  from dout[B*N, 2C]
+// dxn[B*N, C] (plain store), dwx/dwf [C,C,3,3], dbx/dbf [C] (accumulate != 0: added to) from dout[B*N, 2C]
 int pa2d_conv3x3x2_bwd(const float* dout, const float* xn, const float* wx, const float* wf, float* dxn, float* dwx,
                        float* dbx, float* dwf, float* dbf, const void* prepacked, void* ws, size_t ws_bytes, int B,
-                       int H, int W, int C, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
+                       int H, int W, int C, int accumulate, int engine, hipStream_t st, hipEvent_t ev_start,
+                       hipEvent_t ev_stop) {
+    if (!engine_ok(engine)) return PA2D_ERR_ARG;
     if (B <= 0) {
+        if (accumulate) return PA2D_OK;
         const size_t wb = sizeof(float) * (size_t)C * C * 9, bb = sizeof(float) * C;
         int rz = pa2d_zero(dwx, wb, st);
         if (!rz) rz = pa2d_zero(dwf, wb, st);
         if (!rz) rz = pa2d_zero(dbx, bb, st);
         return rz ? rz : pa2d_zero(dbf, bb, st);
     }
-    if (ws_bytes < pa2d_conv3x3x2_workspace(B, H, W, C)) return PA2D_ERR_WORKSPACE;
+    if (ws_bytes < pa2d_conv3x3x2_workspace(B, H, W, C, engine)) return PA2D_ERR_WORKSPACE;
     float* scratch = (float*)ws + (size_t)3 * C * 9 * C;
     const int M = B * H * W;
     int rc;
-    const int NT = gemm_mode() == 2 ? 1 : 3;
-    const size_t apl = conv_planes_bytes(M, C, 2 * C), xpl = conv_xplanes_bytes(M, C);
-    void* const planes = (char*)ws + pa2d_conv3x3x2_workspace(B, H, W, C) - apl - xpl;     // dOut planes
+    const int NT = engine == 2 ? 1 : 3;
+    const size_t apl = conv_planes_bytes(engine, M, C, 2 * C), xpl = conv_xplanes_bytes(engine, M, C);
+    void* const planes = (char*)ws + pa2d_conv3x3x2_workspace(B, H, W, C, engine) - apl - xpl;     // dOut planes
     void* const xplanes = (char*)planes + apl;                                               // X planes
     if (apl && (dxn || xpl)) {
         rc = launch_split_planes(dout, 2 * C, planes, M, 2 * C, NT, st);
@@ -272,11 +288,12 @@ int pa2d_conv3x3x2_bwd(const float* dout, const float* xn, const float* wx, cons
     if (dxn) {
         const float* pack = (const float*)prepacked;
         if (!pack) {
-            rc = conv_pack(wx, wf, (float*)ws, M, C, 1, st);
+            rc = conv_pack(wx, wf, (float*)ws, M, C, 1, engine, st);
             if (rc) return rc;
             pack = (const float*)ws;
         }
         KCParams p = {};
+        p.engine = engine;
         p.A = apl ? (const float*)planes : dout; p.apre = apl ? 1 : 0;
         p.lda = 2 * C; p.B = pack; p.ldb = 9 * 2 * C; p.C = dxn; p.ldc = C;
         p.M = M; p.N = C; p.K = 9 * 2 * C; p.H = H; p.W = W; p.Cin = 2 * C;
@@ -289,12 +306,12 @@ int pa2d_conv3x3x2_bwd(const float* dout, const float* xn, const float* wx, cons
         if (rc) return rc;
         rc = launch_mc_planes(planes, xplanes, C, C, M, H, W, scratch, pl, NT, st);
     } else {
-        rc = launch_mc(dout, 2 * C, 2 * C, xn, C, 9 * C, M, true, H, W, C, scratch, pl, st);
+        rc = launch_mc(dout, 2 * C, 2 * C, xn, C, 9 * C, M, true, H, W, C, scratch, pl, engine, st);
     }
     if (rc) return rc;
-    rc = launch_reduce(scratch, pl.splits, (long long)2 * C * 9 * C, dwx, dwf, 1, C, C, st);
+    rc = launch_reduce(scratch, pl.splits, (long long)2 * C * 9 * C, dwx, dwf, 1, C, C, st, accumulate);
     if (rc) return rc;
-    return launch_colsum(dout, 2 * C, M, 2 * C, dbx, scratch, st, dbf, C);
+    return launch_colsum(dout, 2 * C, M, 2 * C, dbx, scratch, st, dbf, C, accumulate);
 }
 
 }  // extern "C"

@@ -24,6 +24,7 @@ struct KCParams {
     unsigned a_bytes, b_bytes;   // extents of A and B for the buffer descriptors (filled by launch_kc)
     unsigned c_bytes, res_bytes, aux_bytes;
     int apre;   // split engine: A already holds the NT bf16 planes of every 32-channel chunk (split_planes_kernel)
+    int engine; // PA2D_ENGINE_* of this call (explicit per call: the library keeps no engine state)
 };
 
 __device__ __forceinline__ float gelu_f(float x) { return gelu_exact(x); }
@@ -119,8 +120,7 @@ struct MCPlan { int big; int splits; int chunks_per_split; size_t slab_floats; }
 struct KCTile { int bm, bn, bk; };
 
 // engine selection / tile choice (pa2d_gemm.hip)
-int gemm_mode();
-bool use_split(int N, bool im2col, int Cin);
+bool use_split(int engine, int N, bool im2col, int Cin);
 KCTile kc_tile(int M, int N, bool im2col, int Cin);
 // exact fp32 engine (pa2d_gemm_kc.hip): launches the tile variant `t` on a filled-in KCParams
 int launch_kc_f32(const KCParams& p, bool im2col, const KCTile& t, hipStream_t st);
@@ -132,9 +132,10 @@ int launch_repack_split(const float* w0, const float* w1, void* dst, int bwd, in
 // weight-gradient engine and reductions (pa2d_gemm_mc.hip)
 MCPlan plan_mc(int Mi, int Nj, int Mk);
 int launch_mc(const float* A, long long lda, int Mi, const float* B, long long ldb, int Nj, int Mk, bool im2col,
-              int H, int W, int Cin, float* slab, const MCPlan& pl, hipStream_t st);
+              int H, int W, int Cin, float* slab, const MCPlan& pl, int engine, hipStream_t st);
+// accumulate != 0: out += sum of slabs (gradient accumulation straight into the caller's buffer)
 int launch_reduce(const float* slab, int nslab, long long count, float* out, float* out2, int mode, int C, int Cin,
-                  hipStream_t st);
+                  hipStream_t st, int accumulate = 0);
 int pa2d_launch_reduce(const float* slab, int nslab, long long count, float* out, hipStream_t st);
 // weight gradient from pre-split planes (pa2d_gemm_mc_planes.hip)
 bool mc_planes_supported(int C, int Cin);
@@ -142,4 +143,4 @@ int launch_mc_planes(const void* PA, const void* PB, int C, int Cin, int Mk, int
                      const MCPlan& pl, int NT, hipStream_t st);
 int colsum_blocks(int M);
 int launch_colsum(const float* X, long long ld, int M, int N, float* out, float* partial, hipStream_t st,
-                  float* out2 = nullptr, int split = 0);
+                  float* out2 = nullptr, int split = 0, int accumulate = 0);

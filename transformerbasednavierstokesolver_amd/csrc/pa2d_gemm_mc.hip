@@ -245,7 +245,7 @@ MCPlan plan_mc(int Mi, int Nj, int Mk) {
 // 4 independent loads in flight; the 4 lane sums are added in fixed order (deterministic).
 __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restrict__ slab, int nslab, long long count,
                                                            float* __restrict__ out, float* __restrict__ out2,
-                                                           int mode, int C, int Cin) {
+                                                           int mode, int C, int Cin, int accumulate) {
     __shared__ float red[4][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const long long idx = (long long)blockIdx.x * 64 + tx;
@@ -265,21 +265,22 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
     __syncthreads();
     if (ty != 0 || idx >= count) return;
     const float s = ((red[0][tx] + red[1][tx]) + red[2][tx]) + red[3][tx];
+    float* dst;
     if (mode == 0) {
-        out[idx] = s;
+        dst = out + idx;
     } else if (mode == 2) {      // one vector split over two outputs at element C
-        if (idx < C) out[idx] = s; else out2[idx - C] = s;
+        dst = idx < C ? out + idx : out2 + (idx - C);
     } else {
         const int ci = (int)(idx % Cin);
         const int tap = (int)((idx / Cin) % 9);
         const int co = (int)(idx / ((long long)Cin * 9));
-        float* dst = co < C ? out : out2;
-        dst[((size_t)(co % C) * Cin + ci) * 9 + tap] = s;
+        dst = (co < C ? out : out2) + ((size_t)(co % C) * Cin + ci) * 9 + tap;
     }
+    *dst = accumulate ? *dst + s : s;
 }
 
 int launch_mc(const float* A, long long lda, int Mi, const float* B, long long ldb, int Nj, int Mk,
-                     bool im2col, int H, int W, int Cin, float* slab, const MCPlan& pl, hipStream_t st) {
+                     bool im2col, int H, int W, int Cin, float* slab, const MCPlan& pl, int engine, hipStream_t st) {
     if ((Mi & 3) || (Nj & 3) || (lda & 3) || (ldb & 3)) return PA2D_ERR_ARG;
     if (im2col && (Cin & 3)) return PA2D_ERR_UNSUPPORTED;
     MCParams p;
@@ -294,13 +295,13 @@ int launch_mc(const float* A, long long lda, int Mi, const float* B, long long l
     }
     const int bm = pl.big ? 128 : 64;
     const dim3 grid(ceil_div(Mi, bm) * ceil_div(Nj, bm) * pl.splits);
-    const bool bf = gemm_mode() == 2;
+    const bool bf = engine == 2;
     static int mc_bk = -1;
     if (mc_bk < 0) { const char* e = getenv("PA2D_MC_BK"); mc_bk = (e && atoi(e) == 32) ? 32 : 16; }
     if (pl.big && !bf && mc_bk == 32 && (pl.chunks_per_split % 2) == 0) {
         if (im2col) hipLaunchKernelGGL((gemm_mc_kernel<128, 128, true, 0, 32>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((gemm_mc_kernel<128, 128, false, 0, 32>), grid, dim3(256), 0, st, p);
-    } else if (pl.big && im2col && gemm_mode() == 1 && (Cin % 32) == 0) {     // 6-term split, fp32 accuracy
+    } else if (pl.big && im2col && engine == 1 && (Cin % 32) == 0) {     // 6-term split, fp32 accuracy
         hipLaunchKernelGGL((gemm_mc_kernel<128, 128, true, 3>), grid, dim3(256), 0, st, p);
     } else if (pl.big && bf) {
         if (im2col) hipLaunchKernelGGL((gemm_mc_kernel<128, 128, true, 1>), grid, dim3(256), 0, st, p);
@@ -317,15 +318,56 @@ int launch_mc(const float* A, long long lda, int Mi, const float* B, long long l
 }
 
 int launch_reduce(const float* slab, int nslab, long long count, float* out, float* out2, int mode,
-                         int C, int Cin, hipStream_t st) {
+                         int C, int Cin, hipStream_t st, int accumulate) {
     const dim3 grid((unsigned)ceil_div_ll(count, 64));
-    hipLaunchKernelGGL(reduce_slabs_kernel, grid, dim3(256), 0, st, slab, nslab, count, out, out2, mode, C, Cin);
+    hipLaunchKernelGGL(reduce_slabs_kernel, grid, dim3(256), 0, st, slab, nslab, count, out, out2, mode, C, Cin,
+                       accumulate);
     PA2D_CHECK_LAUNCH();
     return PA2D_OK;
 }
 
 int pa2d_launch_reduce(const float* slab, int nslab, long long count, float* out, hipStream_t st) {
     return launch_reduce(slab, nslab, count, out, nullptr, 0, 0, 0, st);
+}
+
+// small records (LayerNorm / head / slice / token parameter gradients): one thread per record element, all slabs
+// summed in a fixed order, result routed to its destination segment
+__global__ __launch_bounds__(256) void reduce_segs_kernel(const float* __restrict__ slab, int nslab, long long count,
+                                                          const ReduceSegs segs, int accumulate) {
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const long long idx = (long long)blockIdx.x * 64 + tx;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    if (idx < count) {
+        const float* p = slab + idx;
+        int k = ty;
+        for (; k + 12 < nslab; k += 16) {
+            s0 += p[(size_t)k * count];
+            s1 += p[(size_t)(k + 4) * count];
+            s2 += p[(size_t)(k + 8) * count];
+            s3 += p[(size_t)(k + 12) * count];
+        }
+        for (; k < nslab; k += 4) s0 += p[(size_t)k * count];
+    }
+    red[ty][tx] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (ty != 0 || idx >= count) return;
+    const float s = ((red[0][tx] + red[1][tx]) + red[2][tx]) + red[3][tx];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        if (i < segs.nseg && idx >= segs.begin[i] && idx < segs.begin[i + 1]) {
+            float* d = segs.dst[i] + (idx - segs.begin[i]);
+            *d = accumulate ? *d + s : s;
+        }
+}
+
+int pa2d_launch_reduce_segs(const float* slab, int nslab, long long count, const ReduceSegs& segs, int accumulate,
+                            hipStream_t st) {
+    if (count <= 0) return PA2D_OK;
+    hipLaunchKernelGGL(reduce_segs_kernel, dim3((unsigned)ceil_div_ll(count, 64)), dim3(256), 0, st, slab, nslab, count,
+                       segs, accumulate);
+    PA2D_CHECK_LAUNCH();
+    return PA2D_OK;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -352,10 +394,10 @@ int colsum_blocks(int M) { int b = ceil_div(M, 128); return b > 1024 ? 1024 : (b
 
 // out2 != NULL: columns >= split go to out2[col - split]
 int launch_colsum(const float* X, long long ld, int M, int N, float* out, float* partial, hipStream_t st,
-                         float* out2, int split) {
+                         float* out2, int split, int accumulate) {
     const int nb = colsum_blocks(M);
     const int rpb = ceil_div(M, nb);
     hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, st, X, ld, M, N, rpb, partial);
     PA2D_CHECK_LAUNCH();
-    return launch_reduce(partial, nb, N, out, out2, out2 ? 2 : 0, split, 0, st);
+    return launch_reduce(partial, nb, N, out, out2, out2 ? 2 : 0, split, 0, st, accumulate);
 }

@@ -247,7 +247,7 @@ __global__ __launch_bounds__(512, (BM + BN > 256) ? 1 : 2) void gemm_kc_split_ke
 // NT = 1: bf16 compute); plain GEMMs run only in bf16-compute mode and convert while staging.
 int launch_kc_split(KCParams& p, bool im2col, hipStream_t st) {
     const int tiles_m = ceil_div(p.M, 128), tiles_n = ceil_div(p.N, 128);
-    const bool bf = gemm_mode() == 2;
+    const bool bf = p.engine == 2;
     const int planes = bf ? 1 : 3;
     if (im2col) {
         if (!p.apre) return PA2D_ERR_ARG;

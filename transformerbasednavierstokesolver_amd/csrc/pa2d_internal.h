@@ -122,3 +122,10 @@ static inline int pa2d_zero(void* p, size_t bytes, hipStream_t st) {
 }
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 static inline long long ceil_div_ll(long long a, long long b) { return (a + b - 1) / b; }
+
+// Deterministic second pass of every partial-sum reduction: out = sum over the nslab records of `count` floats each,
+// scattered over up to 4 destination segments (record index range [begin[i], begin[i+1]) -> dst[i]); accumulate != 0
+// adds to the destination instead of overwriting it (gradient accumulation into the caller's bucket).
+struct ReduceSegs { int nseg; long long begin[5]; float* dst[4]; };
+int pa2d_launch_reduce_segs(const float* slab, int nslab, long long count, const ReduceSegs& segs, int accumulate,
+                            hipStream_t st);

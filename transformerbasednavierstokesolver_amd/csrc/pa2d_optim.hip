@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restr
 struct AdamParams {
     float* p; const float* g; float* m; float* v;
     long long n;
-    float lr, beta1, beta2, eps, wd, bias1, bias2_sqrt, max_norm;
+    float lr, beta1, beta2, eps, step, decay, bias2_sqrt, max_norm;
     const float* gnorm_sq;   // device scalar (sum of squares of g) or null
 };
 
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamParams a) {
         const float c = a.max_norm / (sqrtf(*a.gnorm_sq) + 1e-6f);
         coef = c < 1.f ? c : 1.f;
     }
-    const float step = a.lr / a.bias1, decay = 1.f - a.lr * a.wd, omb1 = 1.f - a.beta1, omb2 = 1.f - a.beta2;
+    const float step = a.step, decay = a.decay, omb1 = 1.f - a.beta1, omb2 = 1.f - a.beta2;
     const long long n4 = a.n >> 2;
     float4* p4 = reinterpret_cast<float4*>(a.p);
     const float4* g4 = reinterpret_cast<const float4*>(a.g);
@@ -100,13 +100,16 @@ __global__ __launch_bounds__(256) void rel_l2_fwd_kernel(const float* __restrict
     }
 }
 
-// dpred[b][i] = gout * (pred - y) / (dnorm_b * ynorm_b)     (gout: device scalar, e.g. 1 for sum / 1/B for mean)
+// dpred[b][i] = gout[b] * (pred - y) / (dnorm_b * ynorm_b)   (gout: per-sample upstream gradient, e.g. 1 for sum,
+// 1/B for mean, arbitrary weights with reduction=False).  dnorm_b == 0 (pred == y): the sub-gradient 0, as the
+// backward of torch.norm returns at 0 — never inf/NaN into the flat gradient bucket.
 __global__ __launch_bounds__(256) void rel_l2_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ y,
                                                          const float* __restrict__ dnorm,
                                                          const float* __restrict__ ynorm,
                                                          const float* __restrict__ gout, long long L,
                                                          float* __restrict__ dpred) {
-    const float s = *gout / (dnorm[blockIdx.y] * ynorm[blockIdx.y]);
+    const float dn = dnorm[blockIdx.y];
+    const float s = dn > 0.f ? gout[blockIdx.y] / (dn * ynorm[blockIdx.y]) : 0.f;
     const size_t base = (size_t)blockIdx.y * L;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < L; i += (long long)gridDim.x * 256)
         dpred[base + i] = s * (pred[base + i] - y[base + i]);
@@ -133,16 +136,20 @@ int pa2d_sumsq(const float* g, long long n, float* out, void* ws, size_t ws_byte
 }
 
 // One AdamW step over flat buffers p/g/m/v of n floats (16-byte aligned).  step_index >= 1.
-int pa2d_adamw_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2,
-                    float eps, float weight_decay, int step_index, const float* gnorm_sq, float max_norm,
+// Hyper-parameters travel as double and the bias corrections are evaluated in double on the host, like
+// torch.optim.AdamW's Python scalars (a float powf is off by ~1e-5 relative at step 1).
+int pa2d_adamw_step(float* p, const float* g, float* m, float* v, long long n, double lr, double beta1, double beta2,
+                    double eps, double weight_decay, int step_index, const float* gnorm_sq, float max_norm,
                     hipStream_t st) {
     if (step_index < 1 || ((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v)) & 15)) return PA2D_ERR_ARG;
     if (n <= 0) return PA2D_OK;
     AdamParams a;
-    a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.lr = lr; a.beta1 = beta1; a.beta2 = beta2; a.eps = eps;
-    a.wd = weight_decay; a.max_norm = max_norm; a.gnorm_sq = gnorm_sq;
-    a.bias1 = 1.0f - powf(beta1, (float)step_index);
-    a.bias2_sqrt = sqrtf(1.0f - powf(beta2, (float)step_index));
+    a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.lr = (float)lr; a.beta1 = (float)beta1; a.beta2 = (float)beta2;
+    a.eps = (float)eps; a.max_norm = max_norm; a.gnorm_sq = gnorm_sq;
+    const double bias1 = 1.0 - pow(beta1, (double)step_index);
+    a.step = (float)(lr / bias1);
+    a.decay = (float)(1.0 - lr * weight_decay);
+    a.bias2_sqrt = (float)sqrt(1.0 - pow(beta2, (double)step_index));
     hipLaunchKernelGGL(adamw_kernel, dim3(stream_blocks(n)), dim3(256), 0, st, a);
     PA2D_CHECK_LAUNCH();
     return PA2D_OK;

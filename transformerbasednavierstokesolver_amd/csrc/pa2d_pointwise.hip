@@ -239,9 +239,13 @@ size_t pa2d_layernorm_bwd_workspace(int rows, int C) { return sizeof(float) * ((
 // dres (optional): gradient flowing through the residual branch, added to dx (dx may alias dres)
 int pa2d_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* g,
                        const float* dres, float* dx, float* dg, float* db, void* ws, size_t ws_bytes, int rows, int C,
-                       hipStream_t st) {
+                       int accumulate, hipStream_t st) {
     if ((C & 3) || C > 256 * LN_MAXV) return PA2D_ERR_UNSUPPORTED;
-    if (rows <= 0) { const int rz = pa2d_zero(dg, sizeof(float) * C, st); return rz ? rz : pa2d_zero(db, sizeof(float) * C, st); }
+    if (rows <= 0) {
+        if (accumulate) return PA2D_OK;
+        const int rz = pa2d_zero(dg, sizeof(float) * C, st);
+        return rz ? rz : pa2d_zero(db, sizeof(float) * C, st);
+    }
     if (ws_bytes < pa2d_layernorm_bwd_workspace(rows, C)) return PA2D_ERR_WORKSPACE;
     const int nb = row_blocks(rows);
     const int rpb = ceil_div(rows, nb);
@@ -249,14 +253,11 @@ int pa2d_layernorm_bwd(const float* dy, const float* x, const float* mean, const
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), sizeof(float) * 8 * C, st, dy, x, mean, rstd, g,
                        dres, dx, part, rows, C, rpb);
     PA2D_CHECK_LAUNCH();
-    float* tail = part + (size_t)nb * 2 * C;
-    int rc = pa2d_launch_reduce(part, nb, 2 * C, tail, st);
-    if (rc) return rc;
-    hipError_t e = hipMemcpyAsync(dg, tail, sizeof(float) * C, hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemcpyAsync(db, tail + C, sizeof(float) * C, hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) return (int)e;
-    return PA2D_OK;
+    ReduceSegs segs;
+    segs.nseg = 2;
+    segs.begin[0] = 0; segs.begin[1] = C; segs.begin[2] = 2 * C; segs.begin[3] = segs.begin[4] = 2 * C;
+    segs.dst[0] = dg; segs.dst[1] = db; segs.dst[2] = segs.dst[3] = nullptr;
+    return pa2d_launch_reduce_segs(part, nb, 2 * C, segs, accumulate, st);
 }
 
 int pa2d_head_fwd(const float* xn, const float* w, const float* b, float* y, int rows, int C, int out_dim,
@@ -278,9 +279,13 @@ size_t pa2d_head_bwd_workspace(int rows, int C, int out_dim) {
 }
 
 int pa2d_head_bwd(const float* dy, const float* xn, const float* w, float* dxn, float* dw, float* db, void* ws,
-                  size_t ws_bytes, int rows, int C, int out_dim, hipStream_t st) {
+                  size_t ws_bytes, int rows, int C, int out_dim, int accumulate, hipStream_t st) {
     if ((C & 3) || out_dim < 1 || out_dim > 8) return PA2D_ERR_UNSUPPORTED;
-    if (rows <= 0) { const int rz = pa2d_zero(dw, sizeof(float) * out_dim * C, st); return rz ? rz : pa2d_zero(db, sizeof(float) * out_dim, st); }
+    if (rows <= 0) {
+        if (accumulate) return PA2D_OK;
+        const int rz = pa2d_zero(dw, sizeof(float) * out_dim * C, st);
+        return rz ? rz : pa2d_zero(db, sizeof(float) * out_dim, st);
+    }
     if (ws_bytes < pa2d_head_bwd_workspace(rows, C, out_dim)) return PA2D_ERR_WORKSPACE;
     const int rec = out_dim * C + out_dim;
     const size_t smem = sizeof(float) * 4 * rec;
@@ -293,14 +298,11 @@ int pa2d_head_bwd(const float* dy, const float* xn, const float* w, float* dxn, 
     else if (out_dim <= 4) hipLaunchKernelGGL((head_bwd_kernel<4>), dim3(nb), dim3(256), smem, st, dy, xn, w, dxn, part, rows, C, out_dim, rpb);
     else hipLaunchKernelGGL((head_bwd_kernel<8>), dim3(nb), dim3(256), smem, st, dy, xn, w, dxn, part, rows, C, out_dim, rpb);
     PA2D_CHECK_LAUNCH();
-    float* tail = part + (size_t)nb * rec;
-    int rc = pa2d_launch_reduce(part, nb, rec, tail, st);
-    if (rc) return rc;
-    hipError_t e = hipMemcpyAsync(dw, tail, sizeof(float) * out_dim * C, hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemcpyAsync(db, tail + out_dim * C, sizeof(float) * out_dim, hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) return (int)e;
-    return PA2D_OK;
+    ReduceSegs segs;
+    segs.nseg = 2;
+    segs.begin[0] = 0; segs.begin[1] = (long long)out_dim * C; segs.begin[2] = rec; segs.begin[3] = segs.begin[4] = rec;
+    segs.dst[0] = dw; segs.dst[1] = db; segs.dst[2] = segs.dst[3] = nullptr;
+    return pa2d_launch_reduce_segs(part, nb, rec, segs, accumulate, st);
 }
 
 int pa2d_act_bwd(const float* dy, const float* pre, float* out, long long n, int act, hipStream_t st) {
@@ -312,6 +314,6 @@ int pa2d_act_bwd(const float* dy, const float* pre, float* out, long long n, int
     return PA2D_OK;
 }
 
-const char* pa2d_version(void) { return "pa2d 0.1 gfx950 fp32-mfma"; }
+const char* pa2d_version(void) { return "pa2d 0.2 gfx950"; }
 
 }  // extern "C"

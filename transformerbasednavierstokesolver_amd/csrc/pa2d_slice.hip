@@ -608,14 +608,15 @@ __global__ __launch_bounds__(256) void slice_bwd_kernel(const SliceBwdParams p) 
 // dtemperature[h] = mask(0.1 <= t <= 5) * sum over (b, chunk) of the per-block dtau partials
 __global__ void dtau_finalize_kernel(const float* __restrict__ part, const float* __restrict__ temperature,
                                      float* __restrict__ dtemp, int B, int heads, int nchunk, int stride, int off,
-                                     int clamp) {
+                                     int clamp, int accumulate) {
     const int hh = blockIdx.x * blockDim.x + threadIdx.x;
     if (hh >= heads) return;
     float s = 0.f;
     for (int b = 0; b < B; ++b)
         for (int c = 0; c < nchunk; ++c) s += part[(size_t)((b * heads + hh) * nchunk + c) * stride + off];
     const float t = temperature[hh];
-    dtemp[hh] = (!clamp || (t >= 0.1f && t <= 5.0f)) ? s : 0.f;
+    const float v = (!clamp || (t >= 0.1f && t <= 5.0f)) ? s : 0.f;
+    dtemp[hh] = accumulate ? dtemp[hh] + v : v;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -692,7 +693,8 @@ static int ppc_for(int N, int nchunk) { return ceil_div(ceil_div(N, nchunk), 16)
 // spart [B,heads,nchunk,M,D], npart [B,heads,nchunk,M] (NULL to skip the norm)
 int pa2d_slice_scatter(const float* xm, long long ldx, const float* v, long long ldv, const float* ws,
                        const float* bs, const float* temperature, float* spart, float* npart, int B, int N,
-                       int heads, int D, int M, int clamp_temperature, hipStream_t st) {
+                       int heads, int D, int M, int clamp_temperature, hipStream_t st, hipEvent_t ev_start,
+                       hipEvent_t ev_stop) {
     const int mt = mt_for(M);
     if ((ldx & 3) || (D & 7)) return PA2D_ERR_ARG;
     if (B <= 0 || N <= 0) return PA2D_OK;
@@ -709,15 +711,17 @@ int pa2d_slice_scatter(const float* xm, long long ldx, const float* v, long long
         p.x_bytes = (unsigned)xb; p.v_bytes = (unsigned)vb;
     }
     const int grid = B * heads * p.nchunk;
+    if (ev_start && hipEventRecord(ev_start, st) != hipSuccess) return PA2D_ERR_ARG;
 #define CALL_SC(D_, MT_) launch_scatter_t<D_, MT_>(p, grid, st)
     DISPATCH_D(CALL_SC)
     PA2D_CHECK_LAUNCH();
+    if (ev_stop && hipEventRecord(ev_stop, st) != hipSuccess) return PA2D_ERR_ARG;
     return PA2D_OK;
 }
 
 int pa2d_deslice_fwd(const float* xm, long long ldx, const float* o, const float* ws, const float* bs,
                      const float* temperature, float* y, long long ldy, int B, int N, int heads, int D, int M,
-                     int clamp_temperature, hipStream_t st) {
+                     int clamp_temperature, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const int mt = mt_for(M);
     if ((ldx & 3) || (ldy & 3) || (D & 7)) return PA2D_ERR_ARG;
     if (B <= 0 || N <= 0) return PA2D_OK;
@@ -734,9 +738,11 @@ int pa2d_deslice_fwd(const float* xm, long long ldx, const float* o, const float
         p.x_bytes = (unsigned)xb; p.y_bytes = (unsigned)yb;
     }
     const int grid = B * heads * p.nchunk;
+    if (ev_start && hipEventRecord(ev_start, st) != hipSuccess) return PA2D_ERR_ARG;
 #define CALL_DS(D_, MT_) launch_deslice_t<D_, MT_>(p, grid, st)
     DISPATCH_D(CALL_DS)
     PA2D_CHECK_LAUNCH();
+    if (ev_stop && hipEventRecord(ev_stop, st) != hipSuccess) return PA2D_ERR_ARG;
     return PA2D_OK;
 }
 
@@ -750,10 +756,12 @@ int pa2d_slice_bwd_points(const float* xm, long long ldx, const float* fm, long 
                           long long lddy, const float* ws, const float* bs, const float* temperature,
                           const float* o, const float* ds, const float* dn, float* dxm, long long lddx, float* dfm,
                           long long lddf, float* dws, float* dbs, float* dtemperature, void* ws_buf, size_t ws_bytes,
-                          int B, int N, int heads, int D, int M, int clamp_temperature, hipStream_t st) {
+                          int B, int N, int heads, int D, int M, int clamp_temperature, int accumulate, hipStream_t st,
+                          hipEvent_t ev_start, hipEvent_t ev_stop) {
     const int mt = mt_for(M);
     if ((ldx & 3) || (ldf & 3) || (lddy & 3) || (lddx & 3) || (lddf & 3) || (D & 7)) return PA2D_ERR_ARG;
     if (B <= 0 || N <= 0) {
+        if (accumulate) return PA2D_OK;
         int rz = pa2d_zero(dws, sizeof(float) * M * D, st);
         if (!rz) rz = pa2d_zero(dbs, sizeof(float) * M, st);
         return rz ? rz : pa2d_zero(dtemperature, sizeof(float) * heads, st);
@@ -777,21 +785,23 @@ int pa2d_slice_bwd_points(const float* xm, long long ldx, const float* fm, long 
     }
     const int grid = B * heads * p.nchunk;
     int rc = PA2D_OK;
+    if (ev_start && hipEventRecord(ev_start, st) != hipSuccess) return PA2D_ERR_ARG;
 #define CALL_BW(D_, MT_) rc = launch_bwd_t<D_, MT_>(p, grid, st)
     DISPATCH_D(CALL_BW)
     if (rc) return rc;
     PA2D_CHECK_LAUNCH();
-    // sum the per-block records [dWs | dbs | dtau] into one record appended behind them
+    if (ev_stop && hipEventRecord(ev_stop, st) != hipSuccess) return PA2D_ERR_ARG;
+    // sum the per-block records [dWs | dbs | dtau] straight into dws / dbs (the dtau column is finalised below)
     const int stride = M * D + M + 1;
-    float* tail = p.part + (size_t)grid * stride;
-    rc = pa2d_launch_reduce(p.part, grid, stride, tail, st);
+    ReduceSegs segs;
+    segs.nseg = 2;
+    segs.begin[0] = 0; segs.begin[1] = (long long)M * D; segs.begin[2] = (long long)M * D + M;
+    segs.begin[3] = segs.begin[4] = segs.begin[2];
+    segs.dst[0] = dws; segs.dst[1] = dbs; segs.dst[2] = segs.dst[3] = nullptr;
+    rc = pa2d_launch_reduce_segs(p.part, grid, stride, segs, accumulate, st);
     if (rc) return rc;
-    hipError_t e = hipMemcpyAsync(dws, tail, sizeof(float) * M * D, hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemcpyAsync(dbs, tail + M * D, sizeof(float) * M, hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(dtau_finalize_kernel, dim3(ceil_div(heads, 64)), dim3(64), 0, st, p.part, temperature,
-                       dtemperature, B, heads, p.nchunk, stride, M * D + M, clamp_temperature);
+                       dtemperature, B, heads, p.nchunk, stride, M * D + M, clamp_temperature, accumulate);
     PA2D_CHECK_LAUNCH();
     return PA2D_OK;
 }

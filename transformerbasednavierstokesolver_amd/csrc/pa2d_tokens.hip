@@ -299,14 +299,16 @@ int pa2d_token_attn_fwd(const float* spart, const float* npart, const float* wq,
 }
 
 size_t pa2d_token_attn_bwd_workspace(int BH, int D) { return sizeof(float) * ((size_t)BH + 1) * 3 * D * D; }
+// dwq/dwk/dwv (+)= (accumulate != 0: added to what they hold)
 
 // dopart: phase-A partials of dO = W^T dY.  Outputs ds, dn per (b,h) and fully reduced dwq/dwk/dwv [D,D].
 int pa2d_token_attn_bwd(const float* s, const float* nrm, const float* wq, const float* wk, const float* wv,
                         const float* dopart, float* ds, float* dn, float* dwq, float* dwk, float* dwv, void* ws,
-                        size_t ws_bytes, int BH, int nchunk, int M, int D, hipStream_t st) {
+                        size_t ws_bytes, int BH, int nchunk, int M, int D, int accumulate, hipStream_t st) {
     const size_t smem = pa2d_token_attn_lds_bytes(M, D, 1);
     if (smem > 160 * 1024 || M > 128 || (D & 3)) return PA2D_ERR_UNSUPPORTED;
     if (BH <= 0) {
+        if (accumulate) return PA2D_OK;
         const size_t wb = sizeof(float) * (size_t)D * D;
         int rz = pa2d_zero(dwq, wb, st);
         if (!rz) rz = pa2d_zero(dwk, wb, st);
@@ -323,20 +325,12 @@ int pa2d_token_attn_bwd(const float* s, const float* nrm, const float* wq, const
     p.dwpart = (float*)ws; p.M = M; p.D = D; p.nchunk = nchunk;
     hipLaunchKernelGGL(token_attn_bwd_kernel, dim3(BH), dim3(TOK_THREADS), smem, st, p);
     PA2D_CHECK_LAUNCH();
-    const size_t dd = (size_t)D * D;
-    if (dwk == dwq + dd && dwv == dwq + 2 * dd)      // the three outputs are one [3,D,D] block: reduce in place
-        return pa2d_launch_reduce((const float*)ws, BH, (long long)3 * dd, dwq, st);
-    float* tail = (float*)ws + (size_t)BH * 3 * dd;
-    int rc = pa2d_launch_reduce((const float*)ws, BH, (long long)3 * dd, tail, st);
-    if (rc) return rc;
-    const size_t n = sizeof(float) * dd;
-    hipError_t e = hipMemcpyAsync(dwq, tail, n, hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemcpyAsync(dwk, tail + dd, n, hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) return (int)e;
-    e = hipMemcpyAsync(dwv, tail + 2 * dd, n, hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) return (int)e;
-    return PA2D_OK;
+    const long long dd = (long long)D * D;
+    ReduceSegs segs;
+    segs.nseg = 3;
+    segs.begin[0] = 0; segs.begin[1] = dd; segs.begin[2] = 2 * dd; segs.begin[3] = 3 * dd; segs.begin[4] = 3 * dd;
+    segs.dst[0] = dwq; segs.dst[1] = dwk; segs.dst[2] = dwv; segs.dst[3] = nullptr;
+    return pa2d_launch_reduce_segs((const float*)ws, BH, 3 * dd, segs, accumulate, st);
 }
 
 }  // extern "C"

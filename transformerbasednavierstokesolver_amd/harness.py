@@ -23,7 +23,19 @@ from .model.Transolver_Structured_Mesh_2D import Model
 from .utils.testloss import TestLoss
 
 
-def build_model(cfg, state_dict=None, device="cuda"):
+def build_model(cfg, state_dict=None, device="cuda", engine=None):
+    """`engine`: GEMM engine of this model ("f32" | "split" | "bf16"; None = PA2D_GEMM / the split default)."""
+    m = _build_model(cfg, state_dict, device)
+    return m.set_engine(engine) if engine is not None else m
+
+
+def model_engine(model):
+    """The resolved GEMM engine id of a (possibly SOL-wrapped) Transolver."""
+    inner = getattr(model, "transolver_model", model)
+    return ops.resolve_engine(getattr(inner, "engine", None))
+
+
+def _build_model(cfg, state_dict, device):
     m = Model(space_dim=cfg["space_dim"], n_layers=cfg["n_layers"], n_hidden=cfg["n_hidden"],
               dropout=cfg.get("dropout", 0.0), n_head=cfg["n_head"], Time_Input=cfg["Time_Input"],
               act=cfg.get("act", "gelu"), mlp_ratio=cfg["mlp_ratio"], fun_dim=cfg["fun_dim"],
@@ -75,7 +87,7 @@ def _fold_group(model, bsz, npoints, ncalls):
     r = max((blk.mlp.linear_pre[0].weight.shape[0] for blk in inner.blocks), default=C) / C
     width = int(max(2, r) * C)
     row_bytes = 4 * width
-    if ops._L().pa2d_get_gemm_mode() == 1:      # split engine: the 2C-wide conv gradient travels as 3 bf16 planes
+    if model_engine(model) == ops.ENGINE_SPLIT:      # split engine: the 2C-wide conv gradient travels as 3 bf16 planes
         row_bytes = max(row_bytes, 6 * 2 * C)
     rows = FOLD_MAX_BYTES // row_bytes
     return max(1, min(ncalls, rows // max(1, bsz * npoints)))
@@ -160,6 +172,9 @@ class GraphedRollout:
             with torch.no_grad(), torch.cuda.graph(self.graph):
                 self._step_eager()
         self.fx.copy_(fx)
+        # the captured launches hold raw parameter pointers: anything that re-seats parameter storage afterwards
+        # (an optimizer that flattens the parameters, .to(), load with assign=True) invalidates the graph
+        self._param_ptrs = [p.data_ptr() for p in model.parameters()]
 
     def _step_eager(self):
         self.im = self.model(self.x, fx=self.fx)
@@ -170,6 +185,9 @@ class GraphedRollout:
 
     @torch.no_grad()
     def run(self, fx0, nsteps):
+        if [p.data_ptr() for p in self.model.parameters()] != self._param_ptrs:
+            raise RuntimeError("parameter storage moved since this rollout graph was captured (e.g. FusedAdamW / "
+                               "FlatGradSync built afterwards, or .to()); build the optimizer first or re-capture")
         self.fx.copy_(fx0)
         self.packs.refresh()
         frames = []
@@ -202,10 +220,8 @@ class GraphedTrainStep:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(warmup):           # builds the flat buffers, sets kernel attributes, warms the allocator
+            for _ in range(warmup):           # sets kernel attributes, warms the allocator
                 self._fwd_bwd()
-                if optimizer.flat_p is None:
-                    optimizer._build()
         torch.cuda.current_stream().wait_stream(side)
         for p, q in zip(model.parameters(), snap):     # warm-up must not move the weights
             p.data.copy_(q)

@@ -30,6 +30,7 @@ class Physics_Attention_Structured_Mesh_2D(nn.Module):
         self.temperature = nn.Parameter(torch.ones([1, heads, 1, 1]) * 0.5)
         self.H = H
         self.W = W
+        self.engine = None      # GEMM engine (None = pa2d_default_engine()); TransolverBase.set_engine sets it
 
         self.in_project_x = nn.Conv2d(dim, inner_dim, kernel, 1, kernel // 2)
         self.in_project_fx = nn.Conv2d(dim, inner_dim, kernel, 1, kernel // 2)
@@ -53,4 +54,5 @@ class Physics_Attention_Structured_Mesh_2D(nn.Module):
         B, N, C = x.shape
         if N != self.H * self.W:
             raise RuntimeError(f"shape '[{B}, {self.H}, {self.W}, {C}]' is invalid for input of size {x.numel()}")
-        return Fn.physics_attention(x, residual, self.H, self.W, self.heads, self.attention_parameters())
+        return Fn.physics_attention(x, residual, self.H, self.W, self.heads, self.attention_parameters(),
+                                    engine=self.engine)

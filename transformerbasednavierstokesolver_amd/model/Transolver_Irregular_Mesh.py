@@ -25,6 +25,7 @@ class Physics_Attention_Irregular_Mesh(nn.Module):
         nn.init.orthogonal_(self.in_project_slice.weight)
         self.to_q, self.to_k, self.to_v = (nn.Linear(dim_head, dim_head, bias=False) for _ in range(3))
         self.to_out = nn.Sequential(nn.Linear(dim, dim), nn.Dropout(dropout))
+        self.engine = None
 
     def attention_parameters(self):
         return (self.temperature, self.in_project_x.weight, self.in_project_x.bias, self.in_project_fx.weight,
@@ -34,7 +35,8 @@ class Physics_Attention_Irregular_Mesh(nn.Module):
     def forward(self, x, residual=None):
         if self.training and self.dropout.p > 0:
             raise NotImplementedError("dropout > 0 is not implemented in the HIP path; refusing to ignore it")
-        return Fn.physics_attention(x, residual, None, None, self.heads, self.attention_parameters())   # H=W=None -> irregular
+        return Fn.physics_attention(x, residual, None, None, self.heads, self.attention_parameters(),
+                                    engine=self.engine)          # H = W = None -> irregular
 
 
 class Transolver_block(BlockBase):

@@ -36,6 +36,7 @@ class MLP(nn.Module):
         if act not in ACTIVATION:
             raise NotImplementedError
         self.act_name, self.res = act, res
+        self.engine = None              # GEMM engine of this module's kernels (None = pa2d_default_engine())
         self.n_input, self.n_hidden, self.n_output, self.n_layers = n_input, n_hidden, n_output, n_layers
         make = ACTIVATION[act]
         self.linear_pre = nn.Sequential(nn.Linear(n_input, n_hidden), make())
@@ -46,12 +47,12 @@ class MLP(nn.Module):
         first, last = self.linear_pre[0], self.linear_post
         x, w_first = pad_contraction(x, first.weight)
         if not self.linears:            # the only shape the Transolver blocks use: one fused pair of GEMMs
-            return Fn.mlp(x, residual, self.act_name, w_first, first.bias, last.weight, last.bias)
-        h = Fn.linear(x, w_first, first.bias, self.act_name)
+            return Fn.mlp(x, residual, self.act_name, w_first, first.bias, last.weight, last.bias, engine=self.engine)
+        h = Fn.linear(x, w_first, first.bias, self.act_name, engine=self.engine)
         for hidden in self.linears:
-            y = Fn.linear(h, hidden[0].weight, hidden[0].bias, self.act_name)
+            y = Fn.linear(h, hidden[0].weight, hidden[0].bias, self.act_name, engine=self.engine)
             h = y + h if self.res else y
-        out = Fn.linear(h, last.weight, last.bias, None)
+        out = Fn.linear(h, last.weight, last.bias, None, engine=self.engine)
         return out if residual is None else out + residual
 
 
@@ -60,6 +61,7 @@ class BlockBase(nn.Module):
 
     def _assemble(self, attn, hidden_dim, act, mlp_ratio, last_layer, out_dim):
         self.last_layer = last_layer
+        self.engine = None
         self.ln_1 = nn.LayerNorm(hidden_dim)
         self.Attn = attn
         self.ln_2 = nn.LayerNorm(hidden_dim)
@@ -74,24 +76,25 @@ class BlockBase(nn.Module):
             raise NotImplementedError("dropout > 0 is not implemented in the HIP path; refusing to ignore it")
         # each residual branch (LayerNorm -> sub-layer -> + fx) is one autograd node
         fx = Fn.attn_branch(fx, self.ln_1.weight, self.ln_1.bias, getattr(attn, "H", None), getattr(attn, "W", None),
-                            attn.heads, attn.attention_parameters())
+                            attn.heads, attn.attention_parameters(), engine=self.engine)
         pre, post = mlp.linear_pre[0], mlp.linear_post
         if mlp.linears or pre.weight.shape[1] % 4:      # generic MLP shapes keep the unfused route
             fx = mlp(Fn.layer_norm(fx, self.ln_2.weight, self.ln_2.bias), residual=fx)
         else:
             fx = Fn.mlp_branch(fx, self.ln_2.weight, self.ln_2.bias, mlp.act_name, pre.weight, pre.bias,
-                               post.weight, post.bias)
+                               post.weight, post.bias, engine=self.engine)
         if not self.last_layer:
             return fx
         z = Fn.layer_norm(fx, self.ln_3.weight, self.ln_3.bias)
         if self.mlp2.out_features <= HEAD_KERNEL_MAX_OUT:
             return Fn.head(z, self.mlp2.weight, self.mlp2.bias)
-        return Fn.linear(z, self.mlp2.weight, self.mlp2.bias, None)
+        return Fn.linear(z, self.mlp2.weight, self.mlp2.bias, None, engine=self.engine)
 
 
 class TransolverBase(nn.Module):
     def _assemble(self, make_block, in_features, n_layers, n_hidden, Time_Input, act):
         self.Time_Input, self.n_hidden = Time_Input, n_hidden
+        self.engine = None
         self.preprocess = MLP(in_features, n_hidden * 2, n_hidden, n_layers=0, res=False, act=act)
         if Time_Input:
             self.time_fc = nn.Sequential(nn.Linear(n_hidden, n_hidden), nn.SiLU(), nn.Linear(n_hidden, n_hidden))
@@ -124,7 +127,17 @@ class TransolverBase(nn.Module):
         (…_2D.py:212-215); that is the same per-point linear map, so it is applied once and broadcast."""
         fc = self.time_fc
         emb = timestep_embedding(T, self.n_hidden)
-        return z + Fn.mlp(emb, None, 'silu', fc[0].weight, fc[0].bias, fc[2].weight, fc[2].bias)
+        return z + Fn.mlp(emb, None, 'silu', fc[0].weight, fc[0].bias, fc[2].weight, fc[2].bias, engine=self.engine)
+
+    def set_engine(self, engine):
+        """Select the GEMM engine ("f32" | "split" | "bf16" | 0 | 1 | 2 | None = environment default) for every
+        kernel of THIS model; other models in the process keep theirs (the library holds no engine state)."""
+        from .. import ops
+        eng = None if engine is None else ops.resolve_engine(engine)
+        for m in self.modules():
+            if hasattr(m, "engine"):
+                m.engine = eng
+        return self
 
     def _run_blocks(self, z):
         for block in self.blocks:

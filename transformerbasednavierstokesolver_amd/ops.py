@@ -4,6 +4,10 @@ PyTorch is used here only as plumbing: it owns device memory (outputs and worksp
 caching allocator, so nothing is allocated inside the native calls) and provides the current HIP
 stream.  Every function takes contiguous fp32 CUDA(HIP) tensors and raises otherwise — there is no
 CPU path (the CPU restatement lives in oracle/ and is test infrastructure only).
+
+Parameter-gradient outputs: every backward op takes `into=` — a tuple of existing gradient buffers (the
+views of the flat gradient bucket) that the kernels ADD to (`accumulate = 1` in the C ABI); without it the
+op allocates fresh tensors and overwrites them.
 """
 from __future__ import annotations
 
@@ -15,13 +19,34 @@ ACT_IDS = {None: 0, "none": 0, "gelu": 1, "tanh": 2, "sigmoid": 3, "relu": 4, "s
 LN_EPS = 1e-5
 
 
-# Optional provider of (hipEvent_t start, hipEvent_t stop) handles recorded around the conv
-# implicit-GEMM launches (bench.py installs one to time the dominant kernel live); None = off.
-conv_event_provider = None
+# Optional provider of (hipEvent_t start, hipEvent_t stop) handles, called as provider(kind) with kind in
+# {"conv", "slice_scatter", "deslice", "slice_bwd"}; libpa2d records them on the launch stream right around that
+# kernel (bench.py installs one to time the roofline kernels live); None = off.
+event_provider = None
 
 
-def _conv_events():
-    return conv_event_provider() if conv_event_provider is not None else (0, 0)
+def _events(kind):
+    return event_provider(kind) if event_provider is not None else (0, 0)
+
+
+# GEMM engines (include/pa2d.h: enum pa2d_engine).  The engine is an explicit argument of every dense op; `None`
+# means pa2d_default_engine() (env PA2D_GEMM=f32|split|bf16, else the fp32-accurate split engine).
+ENGINE_F32, ENGINE_SPLIT, ENGINE_BF16 = 0, 1, 2
+ENGINE_NAMES = {"f32": ENGINE_F32, "split": ENGINE_SPLIT, "bf16": ENGINE_BF16}
+
+
+def default_engine():
+    return _L().pa2d_default_engine()
+
+
+def resolve_engine(engine):
+    if engine is None:
+        return default_engine()
+    if isinstance(engine, str):
+        return ENGINE_NAMES[engine]
+    if engine not in (ENGINE_F32, ENGINE_SPLIT, ENGINE_BF16):
+        raise ValueError(f"unknown GEMM engine {engine!r}")
+    return int(engine)
 
 
 def _L():
@@ -52,6 +77,19 @@ def _ws(nbytes, like):
     return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=like.device)
 
 
+def _grad_outputs(into, shapes, like):
+    """(tensors, accumulate flag): the caller's buffers (added to) or fresh ones (overwritten)."""
+    if into is not None:
+        if len(into) != len(shapes):
+            raise ValueError("`into` must hold one buffer per gradient output")
+        for t, shp in zip(into, shapes):
+            _chk(t)
+            if t.numel() != int(torch.Size(shp).numel()):
+                raise ValueError("gradient buffer of the wrong size")
+        return tuple(into), 1
+    return tuple(torch.empty(shp, dtype=torch.float32, device=like.device) for shp in shapes), 0
+
+
 # ----------------------------------------------------------------------------------------------
 def layernorm_fwd(x2d, gamma, beta, eps=LN_EPS):
     _chk(x2d, gamma, beta)
@@ -64,20 +102,19 @@ def layernorm_fwd(x2d, gamma, beta, eps=LN_EPS):
     return y, mean, rstd
 
 
-def layernorm_bwd(dy, x2d, mean, rstd, gamma, dres=None):
+def layernorm_bwd(dy, x2d, mean, rstd, gamma, dres=None, into=None):
     _chk(dy, x2d, mean, rstd, gamma, dres)
     rows, Cc = x2d.shape
     dx = torch.empty_like(x2d)
-    dg = torch.empty_like(gamma)
-    db = torch.empty_like(gamma)
+    (dg, db), acc = _grad_outputs(into, (gamma.shape, gamma.shape), x2d)
     nb = _L().pa2d_layernorm_bwd_workspace(rows, Cc)
     ws = _ws(nb, x2d)
     _lib.check(_L().pa2d_layernorm_bwd(_p(dy), _p(x2d), _p(mean), _p(rstd), _p(gamma), _p(dres), _p(dx), _p(dg),
-                                       _p(db), ws.data_ptr(), nb, rows, Cc, _stream()), "layernorm_bwd")
+                                       _p(db), ws.data_ptr(), nb, rows, Cc, acc, _stream()), "layernorm_bwd")
     return dx, dg, db
 
 
-def linear_fwd(x2d, w, bias=None, res=None, act=None, want_pre=False):
+def linear_fwd(x2d, w, bias=None, res=None, act=None, want_pre=False, engine=None):
     """y = act(x . w^T + bias) (+ res); returns (y, pre) with pre = pre-activation if want_pre."""
     _chk(x2d, w, bias, res)
     M, K = x2d.shape
@@ -85,11 +122,12 @@ def linear_fwd(x2d, w, bias=None, res=None, act=None, want_pre=False):
     y = torch.empty(M, N, dtype=torch.float32, device=x2d.device)
     pre = torch.empty_like(y) if want_pre else None
     _lib.check(_L().pa2d_gemm_bias_act_fwd(_p(x2d), K, _p(w), w.shape[1], _p(bias), _p(res), N, _p(y), N, _p(pre), N,
-                                           M, N, K, ACT_IDS[act], _stream()), "gemm_bias_act_fwd")
+                                           M, N, K, ACT_IDS[act], resolve_engine(engine), _stream()),
+               "gemm_bias_act_fwd")
     return y, pre
 
 
-def linear_bwd_data(dy, w, pre=None, act=None):
+def linear_bwd_data(dy, w, pre=None, act=None, engine=None):
     """dx = (dy . w) * act'(pre)."""
     _chk(dy, w, pre)
     M, N = dy.shape
@@ -97,40 +135,50 @@ def linear_bwd_data(dy, w, pre=None, act=None):
     dx = torch.empty(M, K, dtype=torch.float32, device=dy.device)
     wt = torch.empty(K * N, dtype=torch.float32, device=dy.device)
     _lib.check(_L().pa2d_gemm_bwd_data(_p(dy), N, _p(w), K, _p(pre), K, ACT_IDS[act], _p(dx), K, _p(wt), M, N, K,
-                                       _stream()), "gemm_bwd_data")
+                                       resolve_engine(engine), _stream()), "gemm_bwd_data")
     return dx
 
 
-def linear_bwd_weight(dy, x2d, want_bias=True):
+def linear_bwd_weight(dy, x2d, want_bias=True, engine=None, into=None):
+    """dw [N,K], db [N] (None if not wanted).  `into` = (dw_buffer, db_buffer or None): accumulate."""
     _chk(dy, x2d)
     M, N = dy.shape
     K = x2d.shape[1]
-    dw = torch.empty(N, K, dtype=torch.float32, device=dy.device)
-    db = torch.empty(N, dtype=torch.float32, device=dy.device) if want_bias else None
-    nb = _L().pa2d_gemm_bwd_weight_workspace(M, N, K)
+    eng = resolve_engine(engine)
+    if into is not None:
+        dw, db = into
+        _chk(dw, db)
+        if dw.numel() != N * K or (db is not None and db.numel() != N):
+            raise ValueError("gradient buffer of the wrong size")
+        if not want_bias:
+            db = None
+        acc = 1
+    else:
+        dw = torch.empty(N, K, dtype=torch.float32, device=dy.device)
+        db = torch.empty(N, dtype=torch.float32, device=dy.device) if want_bias else None
+        acc = 0
+    nb = _L().pa2d_gemm_bwd_weight_workspace(M, N, K, eng)
     ws = _ws(nb, dy)
-    _lib.check(_L().pa2d_gemm_bwd_weight(_p(dy), N, _p(x2d), K, _p(dw), _p(db), ws.data_ptr(), nb, M, N, K,
+    _lib.check(_L().pa2d_gemm_bwd_weight(_p(dy), N, _p(x2d), K, _p(dw), _p(db), ws.data_ptr(), nb, M, N, K, acc, eng,
                                          _stream()), "gemm_bwd_weight")
     return dw, db
 
 
 # ---------------------------------------------------------------------------------------------- conv weight packs
 class _FrozenScope:
-    """Book-keeping of one `weights_frozen()` scope: packs made inside it, keyed by (weights, dims, direction)."""
+    """Book-keeping of one `weights_frozen()` scope: packs made inside it, keyed by (weights, dims, direction,
+    engine) — the pack layout depends on the engine, which is part of the key, so models on different engines
+    can share a scope."""
 
     def __init__(self):
         self.packs = {}
-        self.mode = _L().pa2d_get_gemm_mode()      # pack layout depends on the GEMM engine
 
     def refresh(self):
         """Re-pack every entry in place (same device pointers): called before replaying a hipGraph that was captured
         inside this scope, so the graph's conv launches always see the current weights."""
-        if _L().pa2d_get_gemm_mode() != self.mode:
-            raise RuntimeError("the GEMM engine (pa2d_set_gemm_mode) changed since these weight packs / this hipGraph "
-                               "were made; capture again under the new engine")
-        for (_, _, B, H, W, Cc, direction), (wx, wf, pack) in self.packs.items():
+        for (_, _, B, H, W, Cc, direction, eng), (wx, wf, pack) in self.packs.items():
             _lib.check(_L().pa2d_conv3x3x2_pack(_p(wx), _p(wf), pack.data_ptr(), pack.numel(), B, H, W, Cc, direction,
-                                                _stream()), "conv3x3x2_pack")
+                                                eng, _stream()), "conv3x3x2_pack")
 
 
 _frozen = []      # stack of active scopes
@@ -151,51 +199,51 @@ class weights_frozen:
         return False
 
 
-def _conv_pack(wx, wf, B, H, W, Cc, direction):
+def _conv_pack(wx, wf, B, H, W, Cc, direction, eng):
     """Pack pointer for the active scope (0 = let the conv call pack into its workspace)."""
     if not _frozen:
         return 0
     scope = _frozen[-1]
-    if _L().pa2d_get_gemm_mode() != scope.mode:
-        raise RuntimeError("pa2d_set_gemm_mode() was called inside a weights_frozen() scope")
-    key = (wx.data_ptr(), wf.data_ptr(), B, H, W, Cc, direction)
+    key = (wx.data_ptr(), wf.data_ptr(), B, H, W, Cc, direction, eng)
     hit = scope.packs.get(key)
     if hit is None:
         nb = _L().pa2d_conv3x3x2_pack_bytes(Cc)
         pack = torch.empty(nb, dtype=torch.uint8, device=wx.device)
-        _lib.check(_L().pa2d_conv3x3x2_pack(_p(wx), _p(wf), pack.data_ptr(), nb, B, H, W, Cc, direction, _stream()),
-                   "conv3x3x2_pack")
+        _lib.check(_L().pa2d_conv3x3x2_pack(_p(wx), _p(wf), pack.data_ptr(), nb, B, H, W, Cc, direction, eng,
+                                            _stream()), "conv3x3x2_pack")
         hit = scope.packs[key] = (wx, wf, pack)
     return hit[2].data_ptr()
 
 
-def conv3x3x2_fwd(xn, wx, bx, wf, bf, H, W):
+def conv3x3x2_fwd(xn, wx, bx, wf, bf, H, W, engine=None):
     """xn [B,N,C] -> [B,N,2C] = [x_mid | fx_mid]."""
     _chk(xn, wx, bx, wf, bf)
     B, N, Cc = xn.shape
+    eng = resolve_engine(engine)
     out = torch.empty(B, N, 2 * Cc, dtype=torch.float32, device=xn.device)
-    pre = _conv_pack(wx, wf, B, H, W, Cc, 0)
-    nb = _L().pa2d_conv3x3x2_fwd_workspace(B, H, W, Cc)
+    pre = _conv_pack(wx, wf, B, H, W, Cc, 0, eng)
+    nb = _L().pa2d_conv3x3x2_fwd_workspace(B, H, W, Cc, eng)
     ws = _ws(nb, xn)
-    e0, e1 = _conv_events()
+    e0, e1 = _events("conv")
     _lib.check(_L().pa2d_conv3x3x2_fwd(_p(xn), _p(wx), _p(bx), _p(wf), _p(bf), _p(out), pre, ws.data_ptr(), nb,
-                                       B, H, W, Cc, _stream(), e0, e1), "conv3x3x2_fwd")
+                                       B, H, W, Cc, eng, _stream(), e0, e1), "conv3x3x2_fwd")
     return out
 
 
-def conv3x3x2_bwd(dout, xn, wx, wf, H, W, need_dx=True):
+def conv3x3x2_bwd(dout, xn, wx, wf, H, W, need_dx=True, engine=None, into=None):
+    """Returns (dxn, dwx, dbx, dwf, dbf); `into` = (dwx, dbx, dwf, dbf) buffers to accumulate into."""
     _chk(dout, xn, wx, wf)
     B, N, Cc = xn.shape
+    eng = resolve_engine(engine)
     dxn = torch.empty_like(xn) if need_dx else None
-    dwx, dwf = torch.empty_like(wx), torch.empty_like(wf)
-    dbx = torch.empty(Cc, dtype=torch.float32, device=xn.device)
-    dbf = torch.empty_like(dbx)
-    nb = _L().pa2d_conv3x3x2_workspace(B, H, W, Cc)
+    (dwx, dbx, dwf, dbf), acc = _grad_outputs(into, (wx.shape, (Cc,), wf.shape, (Cc,)), xn)
+    nb = _L().pa2d_conv3x3x2_workspace(B, H, W, Cc, eng)
     ws = _ws(nb, xn)
-    pre = _conv_pack(wx, wf, B, H, W, Cc, 1) if need_dx else 0
-    e0, e1 = _conv_events() if need_dx else (0, 0)
+    pre = _conv_pack(wx, wf, B, H, W, Cc, 1, eng) if need_dx else 0
+    e0, e1 = _events("conv") if need_dx else (0, 0)
     _lib.check(_L().pa2d_conv3x3x2_bwd(_p(dout), _p(xn), _p(wx), _p(wf), _p(dxn), _p(dwx), _p(dbx), _p(dwf), _p(dbf),
-                                       pre, ws.data_ptr(), nb, B, H, W, Cc, _stream(), e0, e1), "conv3x3x2_bwd")
+                                       pre, ws.data_ptr(), nb, B, H, W, Cc, acc, eng, _stream(), e0, e1),
+               "conv3x3x2_bwd")
     return dxn, dwx, dbx, dwf, dbf
 
 
@@ -210,8 +258,10 @@ def slice_scatter(xm, ldx, xm_off, v, ldv, v_off, ws_w, bs, temperature, B, N, h
     nchunk = slice_nchunk(B, N, heads)
     spart = torch.empty(B * heads, nchunk, M, D, dtype=torch.float32, device=xm.device)
     npart = torch.empty(B * heads, nchunk, M, dtype=torch.float32, device=xm.device) if want_norm else None
+    e0, e1 = _events("slice_scatter")
     _lib.check(_L().pa2d_slice_scatter(_p(xm, xm_off), ldx, _p(v, v_off), ldv, _p(ws_w), _p(bs), _p(temperature),
-                                       _p(spart), _p(npart), B, N, heads, D, M, int(clamp), _stream()), "slice_scatter")
+                                       _p(spart), _p(npart), B, N, heads, D, M, int(clamp), _stream(), e0, e1),
+               "slice_scatter")
     return spart, npart
 
 
@@ -226,16 +276,16 @@ def token_attn_fwd(spart, npart, wq, wk, wv):
     return s, nrm, o
 
 
-def token_attn_bwd(s, nrm, wq, wk, wv, dopart):
+def token_attn_bwd(s, nrm, wq, wk, wv, dopart, into=None):
     _chk(s, nrm, wq, wk, wv, dopart)
     BH, nchunk, M, D = dopart.shape
     ds = torch.empty_like(s)
     dn = torch.empty_like(nrm)
-    dwq, dwk, dwv = torch.empty(3, D, D, dtype=torch.float32, device=s.device).unbind(0)   # one block: reduced in place
+    (dwq, dwk, dwv), acc = _grad_outputs(into, ((D, D), (D, D), (D, D)), s)
     nb = _L().pa2d_token_attn_bwd_workspace(BH, D)
     ws = _ws(nb, s)
     _lib.check(_L().pa2d_token_attn_bwd(_p(s), _p(nrm), _p(wq), _p(wk), _p(wv), _p(dopart), _p(ds), _p(dn), _p(dwq),
-                                        _p(dwk), _p(dwv), ws.data_ptr(), nb, BH, nchunk, M, D, _stream()),
+                                        _p(dwk), _p(dwv), ws.data_ptr(), nb, BH, nchunk, M, D, acc, _stream()),
                "token_attn_bwd")
     return ds, dn, dwq, dwk, dwv
 
@@ -243,25 +293,25 @@ def token_attn_bwd(s, nrm, wq, wk, wv, dopart):
 def deslice_fwd(xm, ldx, xm_off, o, ws_w, bs, temperature, B, N, heads, D, M, clamp=True):
     _chk(xm, o, ws_w, bs, temperature)
     y = torch.empty(B, N, heads * D, dtype=torch.float32, device=xm.device)
+    e0, e1 = _events("deslice")
     _lib.check(_L().pa2d_deslice_fwd(_p(xm, xm_off), ldx, _p(o), _p(ws_w), _p(bs), _p(temperature), _p(y), heads * D,
-                                     B, N, heads, D, M, int(clamp), _stream()), "deslice_fwd")
+                                     B, N, heads, D, M, int(clamp), _stream(), e0, e1), "deslice_fwd")
     return y
 
 
-def slice_bwd_points(xf, dy, ws_w, bs, temperature, o, ds, dn, B, N, heads, D, M, clamp=True):
+def slice_bwd_points(xf, dy, ws_w, bs, temperature, o, ds, dn, B, N, heads, D, M, clamp=True, into=None):
     """xf = [B,N,2C] ([x_mid | fx_mid]); returns dxf [B,N,2C], dws, dbs, dtemperature [heads]."""
     _chk(xf, dy, ws_w, bs, temperature, o, ds, dn)
     Cc = heads * D
     dxf = torch.empty_like(xf)
-    dws = torch.empty_like(ws_w)
-    dbs = torch.empty_like(bs)
-    dtemp = torch.empty(heads, dtype=torch.float32, device=xf.device)
+    (dws, dbs, dtemp), acc = _grad_outputs(into, (ws_w.shape, bs.shape, (heads,)), xf)
     nb = _L().pa2d_slice_bwd_workspace(B, N, heads, D, M)
     ws = _ws(nb, xf)
+    e0, e1 = _events("slice_bwd")
     _lib.check(_L().pa2d_slice_bwd_points(_p(xf), 2 * Cc, _p(xf, Cc), 2 * Cc, _p(dy), Cc, _p(ws_w), _p(bs),
                                           _p(temperature), _p(o), _p(ds), _p(dn), _p(dxf), 2 * Cc, _p(dxf, Cc),
                                           2 * Cc, _p(dws), _p(dbs), _p(dtemp), ws.data_ptr(), nb, B, N, heads, D, M,
-                                          int(clamp), _stream()), "slice_bwd_points")
+                                          int(clamp), acc, _stream(), e0, e1), "slice_bwd_points")
     return dxf, dws, dbs, dtemp
 
 
@@ -274,17 +324,16 @@ def head_fwd(xn2d, w, b):
     return y
 
 
-def head_bwd(dy, xn2d, w):
+def head_bwd(dy, xn2d, w, into=None):
     _chk(dy, xn2d, w)
     rows, Cc = xn2d.shape
     O = w.shape[0]
     dxn = torch.empty_like(xn2d)
-    dw = torch.empty_like(w)
-    db = torch.empty(O, dtype=torch.float32, device=w.device)
+    (dw, db), acc = _grad_outputs(into, (w.shape, (O,)), w)
     nb = _L().pa2d_head_bwd_workspace(rows, Cc, O)
     ws = _ws(nb, dy)
     _lib.check(_L().pa2d_head_bwd(_p(dy), _p(xn2d), _p(w), _p(dxn), _p(dw), _p(db), ws.data_ptr(), nb, rows, Cc, O,
-                                  _stream()), "head_bwd")
+                                  acc, _stream()), "head_bwd")
     return dxn, dw, db
 
 
@@ -321,8 +370,11 @@ def rel_l2_fwd(pred2d, y2d):
 
 
 def rel_l2_bwd(pred2d, y2d, dn, yn, gout):
+    """gout: per-sample upstream gradient [B]."""
     _chk(pred2d, y2d, dn, yn, gout)
     B, L = pred2d.shape
+    if gout.numel() != B:
+        raise ValueError("gout must hold one value per sample")
     dpred = torch.empty_like(pred2d)
     _lib.check(_L().pa2d_rel_l2_bwd(_p(pred2d), _p(y2d), _p(dn), _p(yn), _p(gout), _p(dpred), B, L, _stream()),
                "rel_l2_bwd")

@@ -12,7 +12,7 @@ from __future__ import annotations
 
 import numpy as np
 
-__all__ = ["make_config", "state_dict_spec", "synth_state_dict", "synth_ns_fields", "ns_batch",
+__all__ = ["darcy_batch", "DARCY_CONFIG", "make_config", "state_dict_spec", "synth_state_dict", "synth_ns_fields", "ns_batch",
            "meshgrid_pos", "NS_CONFIG", "NS_SMALL_CONFIG", "TINY_CONFIG"]
 
 
@@ -184,3 +184,25 @@ def ns_batch(S, H=64, W=64, T_in=10, T=10, seed=0):
     a = np.ascontiguousarray(f[..., :T_in].reshape(S, H * W, T_in))
     u = np.ascontiguousarray(f[..., T_in:].reshape(S, H * W, T))
     return meshgrid_pos(S, H, W), a, u
+
+
+# BASELINE.json configs[4]: Darcy 421x421 structured mesh, 8 layers, C=128, 8 heads, M=128 slices
+# (exp_darcy.py:118-130 constructor arguments: fun_dim=1, out_dim=1, unified_pos + ref 8 as scripts/Transolver_Darcy.sh).
+DARCY_CONFIG = make_config(n_layers=8, n_hidden=128, n_head=8, slice_num=128, fun_dim=1, out_dim=1, H=421, W=421)
+
+
+def darcy_batch(S, s=421, seed=0):
+    """(pos [S,N,2], coeff [S,N], sol [S,N]) shaped like exp_darcy.py:76-83: `coeff` a piecewise-constant {3, 12}
+    permeability field (thresholded low-passed noise, as the FNO Darcy set), `sol` a smooth O(1e-2) field standing
+    in for the pressure solution (values only need the right shape and smoothness; throughput is value-independent)."""
+    rng = np.random.default_rng(seed)
+    k = np.fft.fftfreq(s, d=1.0 / s)
+    k2 = k[:, None] ** 2 + k[None, :] ** 2
+    coeff = np.empty((S, s * s), dtype=np.float32)
+    sol = np.empty((S, s * s), dtype=np.float32)
+    for i in range(S):
+        g = np.real(np.fft.ifft2(np.fft.fft2(rng.standard_normal((s, s))) * (1.0 + k2 / 9.0) ** -1.0))
+        coeff[i] = np.where(g > 0, 12.0, 3.0).ravel()
+        u = np.real(np.fft.ifft2(np.fft.fft2(rng.standard_normal((s, s))) * (1.0 + k2 / 4.0) ** -1.5))
+        sol[i] = (0.01 * u / u.std() + 0.02).ravel()
+    return meshgrid_pos(S, s, s), coeff, sol
