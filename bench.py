@@ -127,25 +127,38 @@ def cpu_info():
         physical = psutil.cpu_count(logical=False)
     except Exception:
         pass
-    return model, affinity, physical
+    quota = None                      # cgroup CPU quota (cores): the share of the host this process may really use
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = max(1, int(round(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    return model, affinity, physical, quota
 
 
-def cpu_baseline(cfg, sd, pos, a, u, batch, iters, rollouts):
+CPU_SHARE = 16      # cores a 1-GPU box owns; more threads than the share only oversubscribes (measured: 10x slower)
+
+
+def cpu_baseline(cfg, sd, pos, a, u, batch, iters, rollouts, budget_s):
     """BASELINE.md §3 protocol on the oracle (CPU restatement == the reference's algorithm): config C1 (`batch` = 8
     trajectories, fp32), 1 warm-up + `iters` timed FULL exp_ns iterations (10 teacher-forced calls, summed rel-L2,
     backward, AdamW wd=1e-5, OneCycleLR step), then `rollouts` timed 20-step prediction-feedback rollouts (B=1,
     no grad).  Returns a dict (mean and best) plus the warm-up iteration's predictions for the GPU-vs-CPU rel-L2."""
     from oracle import transolver_oracle as orc
-    model, affinity, physical = cpu_info()
-    threads = max(1, min(affinity, physical or affinity))
+    model, affinity, physical, quota = cpu_info()
+    threads = max(1, min(affinity, quota or affinity, CPU_SHARE))
     torch.set_num_threads(threads)
     sdo = orc.to_torch(sd, torch.float32, requires_grad=True)
     live = [k for k in sdo if k != "placeholder"]
     opt = torch.optim.AdamW([sdo[k] for k in live], lr=1e-3, weight_decay=1e-5)
     sched = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=1e-3, total_steps=iters + 4)
     x, fx, yy = (torch.from_numpy(np.ascontiguousarray(t[:batch])) for t in (pos, a, u))
-    times, pred0 = [], None
+    times, pred0, note = [], None, ""
     for it in range(iters + 1):
+        if it >= 2 and (it + 1) * max(times) > budget_s:       # keep the default bench run within minutes
+            note = f" (stopped after {len(times)} timed iterations: {budget_s:.0f} s budget)"
+            break
         t0 = time.perf_counter()
         opt.zero_grad()
         loss, full, pred, grads = orc.train_iteration(sdo, x, fx, yy, cfg)
@@ -156,10 +169,14 @@ def cpu_baseline(cfg, sd, pos, a, u, batch, iters, rollouts):
         dt = time.perf_counter() - t0
         if it == 0:
             pred0 = pred          # initial weights: comparable with the GPU parity sample
+            if dt > budget_s / 2:
+                times, note = [dt], f" (warm-up alone took {dt:.0f} s of the {budget_s:.0f} s budget: it is the sample)"
         else:
             times.append(dt)
         log(f"cpu oracle iteration {it}/{iters} ({'warm-up' if it == 0 else 'timed'}): {dt:.1f} s")
         del grads, loss, full
+        if it == 0 and note:
+            break
     sd_r = orc.to_torch(sd, torch.float32)
     rtimes = []
     with torch.no_grad():
@@ -170,10 +187,10 @@ def cpu_baseline(cfg, sd, pos, a, u, batch, iters, rollouts):
             rtimes.append(time.perf_counter() - t0)
     out = {"value": round(batch / float(np.mean(times)), 5), "unit": "samples/s", "cores": threads, "kind": "port",
            "best": round(batch / float(np.min(times)), 5), "cpu_model": model, "cpu_affinity": affinity,
-           "cpu_physical_cores": physical,
+           "cpu_physical_cores": physical, "cpu_cgroup_quota": quota,
            "sample": f"BASELINE.md §3 protocol: config C1 (B={batch}, fp32, 8 layers, C=256, M=64), 1 warm-up + {iters} "
                      f"timed full exp_ns iterations (10 calls fwd+bwd+AdamW+OneCycle), torch CPU, {threads} threads: "
-                     f"{', '.join(f'{t:.1f}' for t in times)} s",
+                     f"{', '.join(f'{t:.1f}' for t in times)} s{note}",
            "rollout_steps_per_s_b1": round(20.0 / float(np.mean(rtimes)), 3),
            "rollout_steps_per_s_b1_best": round(20.0 / float(np.min(rtimes)), 3),
            "rollout_sample": f"{rollouts} timed 20-step prediction-feedback rollouts of one trajectory, no grad: "
@@ -341,6 +358,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8, help="trajectories of the CPU protocol iteration (config C1: 8)")
     ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--cpu-budget-s", type=float, default=240.0, help="wall-clock budget of the CPU training iterations")
     ap.add_argument("--no-rollout", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="replay forward+backward from one hipGraph (launch-bound small batches); disables the per-kernel HIP events")
@@ -507,7 +525,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         log("cpu baseline: oracle by the BASELINE.md §3 protocol ...")
         cb = min(args.cpu_batch, B)
-        rec, pred_cpu = cpu_baseline(cfg, sd, pos, a, u, cb, args.cpu_iters, 3)
+        rec, pred_cpu = cpu_baseline(cfg, sd, pos, a, u, cb, args.cpu_iters, 3, args.cpu_budget_s)
         out["cpu_baseline"] = rec
         out["rel_l2_gpu_vs_cpu_oracle"] = float((pred_gpu0[:cb].double() - pred_cpu.double()).norm() / pred_cpu.double().norm())
         log(f"CPU oracle: {rec['value']} samples/s, rollout {rec['rollout_steps_per_s_b1']} steps/s at B=1")

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* __restr
 struct AdamParams {
     float* p; const float* g; float* m; float* v;
     long long n;
-    float lr, beta1, beta2, eps, step, decay, bias2_sqrt, max_norm;
+    float lr, beta1, beta2, eps, step, decay, bias2_sqrt, max_norm, omb1, omb2;   // omb = 1 - beta, rounded from double
     const float* gnorm_sq;   // device scalar (sum of squares of g) or null
 };
 
@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamParams a) {
         const float c = a.max_norm / (sqrtf(*a.gnorm_sq) + 1e-6f);
         coef = c < 1.f ? c : 1.f;
     }
-    const float step = a.step, decay = a.decay, omb1 = 1.f - a.beta1, omb2 = 1.f - a.beta2;
+    const float step = a.step, decay = a.decay, omb1 = a.omb1, omb2 = a.omb2;
     const long long n4 = a.n >> 2;
     float4* p4 = reinterpret_cast<float4*>(a.p);
     const float4* g4 = reinterpret_cast<const float4*>(a.g);
@@ -146,6 +146,7 @@ int pa2d_adamw_step(float* p, const float* g, float* m, float* v, long long n, d
     AdamParams a;
     a.p = p; a.g = g; a.m = m; a.v = v; a.n = n; a.lr = (float)lr; a.beta1 = (float)beta1; a.beta2 = (float)beta2;
     a.eps = (float)eps; a.max_norm = max_norm; a.gnorm_sq = gnorm_sq;
+    a.omb1 = (float)(1.0 - beta1); a.omb2 = (float)(1.0 - beta2);      // 1 - float(beta2) would be off by 1e-5 relative
     const double bias1 = 1.0 - pow(beta1, (double)step_index);
     a.step = (float)(lr / bias1);
     a.decay = (float)(1.0 - lr * weight_decay);
