@@ -49,7 +49,7 @@ PEAK_HBM_GBS = 8000.0             # HBM3E, MI355X_MICROARCH.md
 # dominant (conv implicit-GEMM) kernel and the MFMA peak it is priced against, per engine.  Split engine: six bf16
 # MFMA terms per fp32 product -> fp32-equivalent peak = dense bf16 peak / 6.
 CONV_KERNELS = {ops.ENGINE_F32: ("gemm_kc_kernel<128,128,2,2,true,32>", PEAK_FP32_MFMA_TFLOPS),
-                ops.ENGINE_SPLIT: ("gemm_kc_split_kernel<256,128,true,3,true>", round(PEAK_BF16_MFMA_TFLOPS / 6, 1)),
+                ops.ENGINE_SPLIT: ("conv_halo_kernel<3>", round(PEAK_BF16_MFMA_TFLOPS / 6, 1)),
                 ops.ENGINE_BF16: ("gemm_kc_split_kernel<128,128,true,1,true>", PEAK_BF16_MFMA_TFLOPS)}
 ENGINE_LABEL = {ops.ENGINE_F32: "exact fp32 MFMA (all GEMMs)",
                 ops.ENGINE_SPLIT: "3xbf16-split/fp32-acc (conv), exact fp32 MFMA (linears)",

@@ -209,7 +209,30 @@ def test_head(dev, rows, C, O):
     assert rel_l2(db, dy.double().sum(0)) < BWD_TOL
 
 
-def test_bf16_compute_engine_stage_tolerances(dev):
+@pytest.mark.parametrize("policy", ["force", "off"])
+@pytest.mark.parametrize("B,H,W,C", [(2, 64, 64, 256), (1, 21, 17, 128), (2, 16, 16, 64), (1, 12, 20, 192), (3, 8, 32, 32),
+                                     (1, 45, 70, 64), (2, 24, 24, 192), (1, 40, 30, 128)])
+def test_conv_split_engine_both_kernels(dev, monkeypatch, B, H, W, C, policy):
+    """The split engine has two conv kernels: the halo-tile-in-LDS kernel (spatial 8x32 tiles; picked when the launch
+    fills the chip) and the plain implicit-GEMM kernel.  PA2D_CONV_HALO forces either one on shapes with ragged
+    tiles in both directions, several images and 1..8 channel chunks: same fp32 tolerances.  Likewise the weight
+    gradient: 256x256-tile planes kernel (default when 2C >= 256; the last two shapes have ragged row AND column
+    tiles and column groups whose taps change inside a tile) vs the 128x128 one (PA2D_MC_BIG=off)."""
+    monkeypatch.setenv("PA2D_CONV_HALO", policy)
+    if policy == "off":
+        monkeypatch.setenv("PA2D_MC_BIG", "off")
+    _check_conv(dev, B, H, W, C, "split", FWD_TOL, BWD_TOL)
+
+
+def test_bf16_compute_engine_stage_tolerances(dev, monkeypatch):
+    monkeypatch.setenv("PA2D_CONV_HALO", "force")
+    _check_conv(dev, 2, 64, 64, 256, "bf16", 1e-2, 1e-2)
+    _check_conv(dev, 1, 21, 17, 128, "bf16", 1e-2, 1e-2)
+    monkeypatch.delenv("PA2D_CONV_HALO")
+    _bf16_stage_cases(dev)
+
+
+def _bf16_stage_cases(dev):
     """engine "bf16": operands rounded to bf16, one bf16 MFMA term, fp32 accumulate/storage.
     SURVEY 8c: bf16 forward tolerance 3e-2 (the reference under bf16 autocast is 1.4-1.6e-2 from fp64);
     a single GEMM stage stays below 1e-2."""

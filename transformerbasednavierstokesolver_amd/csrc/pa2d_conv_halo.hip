@@ -1,0 +1,263 @@
+// 3x3 implicit-GEMM conv on the bf16 matrix cores with the im2col halo tile RESIDENT in LDS (gfx950 / CDNA4).
+//
+// gemm_kc_split_kernel treats the conv as a plain GEMM over K = (32-channel chunk, tap): every one of the nine taps
+// re-stages the SAME activation pixels (shifted by one) from L2 into LDS, so a 256x128 tile moves 80 KB per K-step
+// and the kernel runs at the ~32 B/clk/CU at which a CU can stage operands (1.31 ms per launch at the bench shape,
+// MFMA floor 0.74 ms).  Here a workgroup owns a SPATIAL tile of 8 x 32 pixels (BM = 256 GEMM rows) x 128 output
+// channels and keeps, per 32-channel chunk, the (8+2) x (32+2) halo tile of the pre-split activation planes in LDS
+// ONCE; the nine taps are nine K-steps that read the MFMA A fragments from that tile at a shifted row offset and
+// only the weight tile (26 KB) is staged per K-step: 34.5 KB instead of 80 KB per K-step (2.3x less L2->LDS
+// traffic), which puts the kernel back under the MFMA roof.
+//
+// Layout (NT = 3 planes: the exact hi+mid+lo split, six MFMA terms, fp32 accuracy; NT = 1: bf16 compute):
+//   A (activations): planes [pixel][Cin/32 chunks][NT][32] bf16 made by split_planes_kernel (p.apre);
+//   B (weights):     pack [n][K-step = chunk*9 + tap][NT][32] bf16 made by repack_split_kernel;
+//   LDS: [halo tile 340 rows | weight stage 0 | weight stage 1], row pitch NT*64 + 16 bytes (an odd number of
+//        16-byte slots: conflict-free ds_read_b128 fragment reads) = 70.7 + 2 x 26.6 KB = 124 KB, one workgroup/CU.
+// Workgroup = 8 waves: waves 4-7 produce (buffer loads -> registers -> LDS, no conversion work), waves 0-3 consume
+// (each a 128-pixel x 64-channel quarter: 4 x 2 tiles of v_mfma_f32_32x32x16_bf16).  The halo tile is single-
+// buffered: the producers fetch chunk c+1 into registers while the consumers run the nine taps of chunk c and
+// store it between two barriers at the chunk boundary (0.2 us per 11.6 us of MFMA work).
+// Zero padding, ragged tiles (any H, W) and the K tail cost nothing: out-of-image pixels are buffer loads with an
+// out-of-range offset (hardware returns 0), out-of-image outputs are stores with an out-of-range offset (dropped).
+#include "pa2d_gemm_common.h"
+
+namespace {
+constexpr int TH = 8, TW = 32, BM = TH * TW, BN = 128;
+constexpr int HH = TH + 2, HWD = TW + 2, HROWS = HH * HWD;          // 10 x 34 = 340 halo pixels
+}
+
+template <int NT>
+__global__ __launch_bounds__(512, 1) void conv_halo_kernel(const KCParams p, const int tiles_x, const int tiles_y,
+                                                           const int nimg) {
+    constexpr int PITCHB = NT * 64 + 16;
+    constexpr int PIECES = NT * 4;                                   // 16-byte pieces per row and chunk
+    constexpr int A_BYTES = HROWS * PITCHB;
+    constexpr int B_STAGE = BN * PITCHB;
+    constexpr int AP_IT = (HROWS * PIECES + 255) / 256;              // halo pieces per producer thread (16 / 6)
+    constexpr int BP_IT = (BN * PIECES) / 256;                       // weight pieces per producer thread (6 / 2)
+    constexpr int TM = 4, TN = 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const a_s = smem;
+    unsigned char* const b_s = smem + A_BYTES;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_m = nimg * tiles_y * tiles_x;
+    const int tmx = (tiles_m + 7) / 8;                               // XCD-contiguous ranges of spatial tiles
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int tile_m = xcd * tmx + slot / tiles_n;
+    const int tile_n = slot % tiles_n;
+    if (tile_m >= tiles_m || slot / tiles_n >= tmx) return;
+    const int img = tile_m / (tiles_y * tiles_x);
+    const int trem = tile_m - img * (tiles_y * tiles_x);
+    const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
+    const int nch = p.Cin / 32;                                      // 32-channel chunks
+    const int nk = nch * 9;
+
+    if (wave >= 4) {
+        // ------------------------------------------------------------------ producers
+        const int ptid = tid - 256;
+        const __amdgpu_buffer_rsrc_t ra_rsrc = make_rsrc(p.A, p.a_bytes);
+        const __amdgpu_buffer_rsrc_t rb_rsrc = make_rsrc(p.B, p.b_bytes);
+        unsigned ap_off[AP_IT], ap_lds[AP_IT];
+#pragma unroll
+        for (int s = 0; s < AP_IT; ++s) {
+            const int q = ptid + 256 * s, row = q / PIECES, piece = q - row * PIECES;
+            const int hy = row / HWD, hx = row - hy * HWD;
+            const int yy = y0 - 1 + hy, xx = x0 - 1 + hx;
+            const bool ok = row < HROWS && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+            ap_off[s] = ok ? ((unsigned)((img * p.H + yy) * p.W + xx) * (unsigned)(nch * PIECES) + piece) * 16u : OOB_OFF;
+            ap_lds[s] = row < HROWS ? (unsigned)(row * PITCHB + piece * 16) : 0xFFFFFFFFu;
+        }
+        unsigned bp_off[BP_IT], bp_lds[BP_IT];
+#pragma unroll
+        for (int s = 0; s < BP_IT; ++s) {
+            const int q = ptid + 256 * s, row = q / PIECES, piece = q - row * PIECES;
+            const int gn = tile_n * BN + row;
+            bp_off[s] = gn < p.N ? ((unsigned)gn * (unsigned)nk * PIECES + piece) * 16u : OOB_OFF;
+            bp_lds[s] = row * PITCHB + piece * 16;
+        }
+        u32x4 rq[AP_IT], rp0[BP_IT], rp1[BP_IT];
+#define HA_LOAD(chunk_)                                                                                    \
+    {                                                                                                      \
+        const unsigned sh_ = (unsigned)(chunk_) * (PIECES * 16u);                                          \
+        _Pragma("unroll") for (int s = 0; s < AP_IT; ++s)                                                  \
+            rq[s] = __builtin_amdgcn_raw_buffer_load_b128(ra_rsrc, ap_off[s] != OOB_OFF ? ap_off[s] + sh_ : OOB_OFF, 0, 0); \
+    }
+#define HA_STORE()                                                                                         \
+    {                                                                                                      \
+        _Pragma("unroll") for (int s = 0; s < AP_IT; ++s)                                                  \
+            if (ap_lds[s] != 0xFFFFFFFFu) *reinterpret_cast<u32x4*>(a_s + ap_lds[s]) = rq[s];              \
+    }
+#define HB_LOAD(kc_, RP)                                                                                   \
+    {                                                                                                      \
+        _Pragma("unroll") for (int s = 0; s < BP_IT; ++s)                                                  \
+            RP[s] = __builtin_amdgcn_raw_buffer_load_b128(                                                 \
+                rb_rsrc, bp_off[s] != OOB_OFF ? bp_off[s] + (unsigned)(kc_) * (PIECES * 16u) : OOB_OFF, 0, 0); \
+    }
+#define HB_STORE(stage_, RP)                                                                               \
+    {                                                                                                      \
+        _Pragma("unroll") for (int s = 0; s < BP_IT; ++s)                                                  \
+            *reinterpret_cast<u32x4*>(b_s + (stage_) * B_STAGE + bp_lds[s]) = RP[s];                       \
+    }
+        HA_LOAD(0)
+        HB_LOAD(0, rp0)
+        if (nk > 1) HB_LOAD(1, rp1)
+        HA_STORE()
+        HB_STORE(0, rp0)
+        if (nch > 1) HA_LOAD(1)
+        if (nk > 2) HB_LOAD(2, rp0)
+        __syncthreads();                                  // #0: halo tile of chunk 0 + weight stage 0 are ready
+        for (int kc = 0; kc < nk; kc += 2) {
+            // consumers run K-step kc on weight stage 0
+            if (kc + 1 < nk) {
+                HB_STORE(1, rp1)
+                if (kc + 3 < nk) HB_LOAD(kc + 3, rp1)
+            }
+            __syncthreads();                              // end of K-step kc
+            if (kc % 9 == 8 && kc + 1 < nk) {             // chunk boundary: swap the halo tile between two barriers
+                HA_STORE()
+                if (kc / 9 + 2 < nch) HA_LOAD(kc / 9 + 2)
+                __syncthreads();
+            }
+            if (kc + 1 < nk) {
+                // consumers run K-step kc+1 on weight stage 1
+                if (kc + 2 < nk) {
+                    HB_STORE(0, rp0)
+                    if (kc + 4 < nk) HB_LOAD(kc + 4, rp0)
+                }
+                __syncthreads();                          // end of K-step kc+1
+                if ((kc + 1) % 9 == 8 && kc + 2 < nk) {
+                    HA_STORE()
+                    if ((kc + 1) / 9 + 2 < nch) HA_LOAD((kc + 1) / 9 + 2)
+                    __syncthreads();
+                }
+            }
+        }
+#undef HA_LOAD
+#undef HA_STORE
+#undef HB_LOAD
+#undef HB_STORE
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumers
+    const int wm = wave >> 1, wn = wave & 1;
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // fragment addresses: lane l holds row (l & 31), k-half (l >> 5) of a 32-row tile.  A rows are the 32 pixels of
+    // image row (wm*4 + i) of the tile, found in the halo tile at [(row + 1 + dy)][1 + dx + pixel].
+    const unsigned a_frag = (unsigned)((((wm * 4 + 1) * HWD) + 1 + (lane & 31)) * PITCHB + (lane >> 5) * 16);
+    const unsigned b_frag = (unsigned)((wn * 64 + (lane & 31)) * PITCHB + (lane >> 5) * 16);
+    __syncthreads();                                      // #0
+    int tap = 0;
+    for (int kc = 0; kc < nk; ++kc) {
+        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+        const unsigned char* af_base = a_s + a_frag + (dy * HWD + dx) * PITCHB;
+        const unsigned char* bf_base = b_s + (kc & 1) * B_STAGE + b_frag;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 af[TM][NT], bf[TN][NT];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int q = 0; q < NT; ++q)
+                    af[i][q] = *reinterpret_cast<const bf16x8*>(af_base + i * (HWD * PITCHB) + q * 64 + ks * 32);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int q = 0; q < NT; ++q)
+                    bf[j][q] = *reinterpret_cast<const bf16x8*>(bf_base + j * 32 * PITCHB + q * 64 + ks * 32);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    if constexpr (NT == 3) {   // smallest terms first
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+                }
+        }
+        __syncthreads();                                  // end of K-step kc
+        if (++tap == 9) {
+            tap = 0;
+            if (kc + 1 < nk) __syncthreads();             // the producers swapped the halo tile in between
+        }
+    }
+
+    // epilogue: out[pixel][col] = acc + bias.  Accumulator register r of lane l is pixel x0 + 4*(l>>5) + (r&3) + 8*(r>>2)
+    // of image row y0 + wm*4 + i, column tile_n*128 + wn*64 + j*32 + (l & 31): 32 lanes write 128 contiguous bytes.
+    const __amdgpu_buffer_rsrc_t rc = make_rsrc(p.C, p.c_bytes);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int col = tile_n * BN + wn * 64 + j * 32 + (lane & 31);
+        const bool col_ok = col < p.N;
+        const float bv = (p.bias && col_ok) ? (col < p.bias_split ? p.bias[col] : p.bias2[col - p.bias_split]) : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int y = y0 + wm * 4 + i;
+            const unsigned rowbase = (unsigned)((img * p.H + y) * p.W);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int x = x0 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
+                const bool ok = col_ok && y < p.H && x < p.W;
+                buf_store1(rc, ok ? ((rowbase + (unsigned)x) * (unsigned)p.ldc + (unsigned)col) * 4u : OOB_OFF,
+                           acc[i][j][r] + bv);
+            }
+        }
+    }
+}
+
+// 0 = never, 1 = when the launch fills the chip (default), 2 = always (tests): env PA2D_CONV_HALO=off|auto|force
+static int halo_policy() {
+    const char* e = getenv("PA2D_CONV_HALO");
+    if (!e || !e[0]) return 1;
+    return e[0] == 'o' ? 0 : (e[0] == 'f' ? 2 : 1);
+}
+
+bool conv_halo_applies(const KCParams& p) {
+    const int pol = halo_policy();
+    if (pol == 0 || !p.apre || (p.Cin % 32) != 0 || p.H <= 0 || p.W <= 0 || (p.M % (p.H * p.W)) != 0) return false;
+    const long long tiles = (long long)(p.M / (p.H * p.W)) * ceil_div(p.H, TH) * ceil_div(p.W, TW) * ceil_div(p.N, BN);
+    return pol == 2 || tiles >= 512;
+}
+
+// p.a_bytes / p.b_bytes must already describe the plane image and the weight pack (launch_kc_split fills them)
+int launch_conv_halo(const KCParams& p, hipStream_t st) {
+    const int NT = p.engine == 2 ? 1 : 3;
+    const int tiles_x = ceil_div(p.W, TW), tiles_y = ceil_div(p.H, TH), nimg = p.M / (p.H * p.W);
+    const int tiles_m = nimg * tiles_y * tiles_x, tiles_n = ceil_div(p.N, BN);
+    const dim3 grid(ceil_div(tiles_m, 8) * 8 * tiles_n);
+    const int pitch = NT * 64 + 16;
+    const int smem = HROWS * pitch + 2 * BN * pitch;
+    static bool attr3 = false, attr1 = false;
+    if (NT == 3) {
+        if (!attr3) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<3>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            if (e != hipSuccess) return (int)e;
+            attr3 = true;
+        }
+        hipLaunchKernelGGL((conv_halo_kernel<3>), grid, dim3(512), smem, st, p, tiles_x, tiles_y, nimg);
+    } else {
+        if (!attr1) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<1>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            if (e != hipSuccess) return (int)e;
+            attr1 = true;
+        }
+        hipLaunchKernelGGL((conv_halo_kernel<1>), grid, dim3(512), smem, st, p, tiles_x, tiles_y, nimg);
+    }
+    PA2D_CHECK_LAUNCH();
+    return PA2D_OK;
+}

@@ -7,7 +7,6 @@
 // split at fp32 accuracy (conv GEMMs; other GEMMs stay exact), 2 = bf16 compute for every GEMM (fp32 accumulate
 // and storage).  pa2d_default_engine() only reads the environment (PA2D_GEMM=f32|split|bf16), default = split.
 static bool engine_ok(int e) { return e >= 0 && e <= 2; }
-// (the split engine serves the conv implicit GEMMs only: the short-K linears gain nothing from it)
 // K-step: 32 (half the barriers of 16, full 128-byte row segments; 3-4 % faster on the conv, ~10 % on the small tiles)
 // whenever the layout allows it: plain GEMMs always, the conv when Cin % 32 == 0; otherwise 16.
 static int kc_bk(bool im2col, int Cin) {
@@ -28,6 +27,9 @@ KCTile kc_tile(int M, int N, bool im2col, int Cin) {
     if (t12864 >= 384 || M <= 64) return {128, 64, bk};
     return {64, 64, bk};
 }
+// (the split engine serves the conv implicit GEMMs only.  Measured round 2: the K = C linears as 6-term splits with
+// operands converted while staging run at the SAME 0.155 ms as on the exact engine — they are bound by their short
+// K loop (8 K-steps between a cold prologue and a 128 KB epilogue), not by the matrix pipe.)
 bool use_split(int engine, int N, bool im2col, int Cin) {
     const int m = engine;
     if (m == 1) return im2col && N > 64 && (Cin % 32) == 0;
@@ -185,17 +187,23 @@ static size_t conv_planes_bytes(int engine, int M, int N, int Cin) {
 }
 
 // bf16 engines: the weight gradient also runs from pre-split planes (of dOut and of X) when the tile shapes allow
-static bool conv_dw_from_planes(int engine, int M, int C) {
-    return conv_planes_bytes(engine, M, C, 2 * C) != 0 && mc_planes_supported(C, C) && plan_mc(2 * C, 9 * C, M).big;
+// 0 = fp32 operands (gather kernel), 1 = planes, 128 x 128 tiles, 2 = planes, 256 x 256 tiles (one round of workgroups)
+static int conv_dw_kind(int engine, int M, int C) {
+    if (conv_planes_bytes(engine, M, C, 2 * C) == 0) return 0;
+    if (mc_planes_big_applies(C, C, M)) return 2;
+    return (mc_planes_supported(C, C) && plan_mc(2 * C, 9 * C, M).big) ? 1 : 0;
+}
+static MCPlan conv_dw_plan(int engine, int M, int C) {
+    return conv_dw_kind(engine, M, C) == 2 ? plan_mc_planes_big(2 * C, 9 * C, M) : plan_mc(2 * C, 9 * C, M);
 }
 static size_t conv_xplanes_bytes(int engine, int M, int C) {
-    return conv_dw_from_planes(engine, M, C) ? ((planes_bytes(M, C, engine == 2 ? 1 : 3) + 255) & ~(size_t)255) : 0;
+    return conv_dw_kind(engine, M, C) ? ((planes_bytes(M, C, engine == 2 ? 1 : 3) + 255) & ~(size_t)255) : 0;
 }
 
 // backward workspace: [weight pack | slabs or column-sum partials | dOut planes | X planes]  (planes: bf16 engines)
 size_t pa2d_conv3x3x2_workspace(int B, int H, int W, int C, int engine) {
     const size_t pack = (size_t)3 * C * 9 * C;      // fp32 pack (2C*9C floats) or 3 bf16 planes (1.5x)
-    const MCPlan pl = plan_mc(2 * C, 9 * C, B * H * W);
+    const MCPlan pl = conv_dw_plan(engine, B * H * W, C);
     size_t sl = pl.slab_floats, cs = (size_t)colsum_blocks(B * H * W) * 2 * C;
     return (pack + (sl > cs ? sl : cs)) * sizeof(float) + conv_planes_bytes(engine, B * H * W, C, 2 * C) +
            conv_xplanes_bytes(engine, B * H * W, C);
@@ -300,11 +308,12 @@ int pa2d_conv3x3x2_bwd(const float* dout, const float* xn, const float* wx, cons
         rc = launch_kc(p, true, st, ev_start, ev_stop);
         if (rc) return rc;
     }
-    const MCPlan pl = plan_mc(2 * C, 9 * C, M);
+    const MCPlan pl = conv_dw_plan(engine, M, C);
     if (xpl) {      // bf16 engines: both operands as pre-split planes, transposed LDS reads, no conversion in the GEMM
         rc = launch_split_planes(xn, C, xplanes, M, C, NT, st);
         if (rc) return rc;
-        rc = launch_mc_planes(planes, xplanes, C, C, M, H, W, scratch, pl, NT, st);
+        rc = pl.big == 2 ? launch_mc_planes_big(planes, xplanes, C, C, M, H, W, scratch, pl, NT, st)
+                         : launch_mc_planes(planes, xplanes, C, C, M, H, W, scratch, pl, NT, st);
     } else {
         rc = launch_mc(dout, 2 * C, 2 * C, xn, C, 9 * C, M, true, H, W, C, scratch, pl, engine, st);
     }

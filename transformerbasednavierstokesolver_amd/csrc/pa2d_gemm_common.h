@@ -129,6 +129,9 @@ int launch_kc_split(KCParams& p, bool im2col, hipStream_t st);
 size_t planes_bytes(long long rows, int C, int NT);
 int launch_split_planes(const float* src, long long ld, void* dst, long long rows, int C, int NT, hipStream_t st);
 int launch_repack_split(const float* w0, const float* w1, void* dst, int bwd, int NT, int C, int Cin, hipStream_t st);
+// conv with the halo tile resident in LDS (pa2d_conv_halo.hip): used by launch_kc_split for pre-split im2col operands
+bool conv_halo_applies(const KCParams& p);
+int launch_conv_halo(const KCParams& p, hipStream_t st);
 // weight-gradient engine and reductions (pa2d_gemm_mc.hip)
 MCPlan plan_mc(int Mi, int Nj, int Mk);
 int launch_mc(const float* A, long long lda, int Mi, const float* B, long long ldb, int Nj, int Mk, bool im2col,
@@ -141,6 +144,11 @@ int pa2d_launch_reduce(const float* slab, int nslab, long long count, float* out
 bool mc_planes_supported(int C, int Cin);
 int launch_mc_planes(const void* PA, const void* PB, int C, int Cin, int Mk, int H, int W, float* slab,
                      const MCPlan& pl, int NT, hipStream_t st);
+// 256 x 256-tile variant (8 waves, one round of workgroups) and its own split plan
+bool mc_planes_big_applies(int C, int Cin, int Mk);
+MCPlan plan_mc_planes_big(int Mi, int Nj, int Mk);
+int launch_mc_planes_big(const void* PA, const void* PB, int C, int Cin, int Mk, int H, int W, float* slab,
+                         const MCPlan& pl, int NT, hipStream_t st);
 int colsum_blocks(int M);
 int launch_colsum(const float* X, long long ld, int M, int N, float* out, float* partial, hipStream_t st,
                   float* out2 = nullptr, int split = 0, int accumulate = 0);

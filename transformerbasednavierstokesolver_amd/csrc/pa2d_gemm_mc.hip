@@ -303,6 +303,7 @@ int launch_mc(const float* A, long long lda, int Mi, const float* B, long long l
         else hipLaunchKernelGGL((gemm_mc_kernel<128, 128, false, 0, 32>), grid, dim3(256), 0, st, p);
     } else if (pl.big && im2col && engine == 1 && (Cin % 32) == 0) {     // 6-term split, fp32 accuracy
         hipLaunchKernelGGL((gemm_mc_kernel<128, 128, true, 3>), grid, dim3(256), 0, st, p);
+
     } else if (pl.big && bf) {
         if (im2col) hipLaunchKernelGGL((gemm_mc_kernel<128, 128, true, 1>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((gemm_mc_kernel<128, 128, false, 1>), grid, dim3(256), 0, st, p);

@@ -207,3 +207,250 @@ int launch_mc_planes(const void* PA, const void* PB, int C, int Cin, int Mk, int
     PA2D_CHECK_LAUNCH();
     return PA2D_OK;
 }
+
+// =============================================================================================================
+// 256 x 256 tile, 8 waves (2 per SIMD), every wave stages AND multiplies: the 128 x 128 kernel above moves 24 KB per 24
+// MFMAs per wave and sits at the ~70 GB/s per CU at which L2 feeds a CU (1.75 ms per launch at the bench shape, MFMA
+// floor 0.74).  Here a workgroup owns 256 dOut channels x 256 columns (= 8 groups of 32 input channels, each group
+// with its own tap, so any Cin % 32 == 0 works) and each wave a 128 x 64 quarter-strip (4 x 2 MFMA tiles): 48 KB per
+// K-step of 16 pixel rows for 8 x 48 MFMAs, i.e. HALF the staging bytes and 3/4 of the LDS fragment reads per MFMA,
+// and 48 MFMAs between barriers instead of 24.  LDS: 2 stages x NT x (8 KB dOut image + 8 KB X image) = 96 KB, one
+// workgroup per CU.  The launch is ONE round of <= 256 workgroups (tiles x splits); workgroups are numbered so that each
+// XCD (blockIdx & 7) owns a contiguous range of (split, i-tile, j-tile): the 9+ workgroups that re-read the same dOut
+// rows and the same X rows (at different tap shifts) sit behind one L2.
+template <int NT, int KS>
+__global__ __launch_bounds__(512, 1) void gemm_mc_planes_big_kernel(const MCPlanesParams p, const int per_xcd) {
+    constexpr int PIMG = 8192;                       // one plane image of one K-step: 16 rows x 512 B (256 bf16 columns)
+    constexpr int STAGE = 2 * NT * KS * PIMG;        // dOut planes then X planes
+    constexpr int NP = (2 * NT * KS * 512) / 512;    // 16-byte pieces per thread and stage (16 rows x 32 pieces x NT x 2 / 512)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tiles_i = (p.Mi + 255) / 256, tiles_j = (p.Nj + 255) / 256;
+    const int tiles = tiles_i * tiles_j;
+    const int lin = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);      // XCD-contiguous numbering
+    if ((int)(blockIdx.x >> 3) >= per_xcd || lin >= tiles * p.splits) return;
+    const int split = lin / tiles, t_ = lin - split * tiles;
+    const int ti = t_ / tiles_j, tj = t_ - ti * tiles_j;
+    const int wm = wave >> 2, wn = wave & 3;         // 2 x 4 waves: 128 rows x 64 columns each
+    const int total_chunks = (p.Mk + 15) / 16;
+    const int c_begin = split * p.chunks_per_split;
+    const int c_end = min(total_chunks, c_begin + p.chunks_per_split);
+    const int HW = p.H * p.W;
+
+    const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.PA), 0, p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.PB), 0, p.b_bytes, 0x00020000);
+
+    // staging assignment: piece q = tid + 512*s: operand, row (16*KS), 32-column group c (8), plane, 16-byte piece (4)
+    int s_row[NP], s_dy[NP], s_dx[NP], s_shift[NP];
+    unsigned s_goff[NP], s_lds[NP];
+    bool s_isb[NP];
+#pragma unroll
+    for (int s = 0; s < NP; ++s) {
+        const int q = tid + 512 * s;
+        const int per_op = 16 * KS * 32 * NT;
+        const int op = q / per_op, r = q - op * per_op;
+        const int row = r / (32 * NT), rr = r - row * (32 * NT);
+        const int c = rr / (4 * NT), pp = rr - c * (4 * NT);
+        const int plane = pp >> 2, piece = pp & 3;
+        s_row[s] = row;
+        s_isb[s] = op != 0;
+        int chunk;
+        bool colok;
+        if (op) {          // X: column group c of this tile = columns jc..jc+31 = one tap, one 32-channel chunk
+            const int jc = tj * 256 + c * 32;
+            const int tap = jc / p.Cin;
+            chunk = (jc - tap * p.Cin) >> 5;
+            colok = jc < p.Nj;
+            s_dy[s] = tap / 3 - 1;
+            s_dx[s] = tap - (tap / 3) * 3 - 1;
+            s_shift[s] = s_dy[s] * p.W + s_dx[s];
+        } else {           // dOut: channels ti*256 + c*32 ..
+            chunk = ((ti * 256) >> 5) + c;
+            colok = ti * 256 + c * 32 < p.Mi;
+            s_dy[s] = s_dx[s] = s_shift[s] = 0;
+        }
+        s_goff[s] = colok ? (unsigned)((chunk * NT + plane) * 64 + piece * 16) : OOB_OFF;
+        const int ch16 = c * 4 + piece;              // 16-byte chunk index inside the 512-byte image row
+        s_lds[s] = (unsigned)(((op * NT + plane) * KS + (row >> 4)) * PIMG) + 512u * (row & 15) +
+                   16u * (ch16 ^ ((((row & 15) & 3) << 2) | (((row & 15) >> 2) & 3)));
+    }
+    u32x4 rg[NP];
+#define MB_LOAD(c_)                                                                                       \
+    {                                                                                                     \
+        const int m0_ = (c_) * 16;                                                                        \
+        _Pragma("unroll") for (int s = 0; s < NP; ++s) {                                                  \
+            const int m_ = m0_ + s_row[s];                                                                \
+            bool ok_ = s_goff[s] != OOB_OFF && m_ < p.Mk && (KS == 1 || (c_) + (s_row[s] >> 4) < c_end);  \
+            int mm_ = m_;                                                                                 \
+            if (s_isb[s]) {                                                                               \
+                const int n_ = m_ % HW;                                                                   \
+                const int y_ = n_ / p.W, x_ = n_ - y_ * p.W;                                              \
+                ok_ = ok_ && (unsigned)(y_ + s_dy[s]) < (unsigned)p.H && (unsigned)(x_ + s_dx[s]) < (unsigned)p.W; \
+                mm_ = m_ + s_shift[s];                                                                    \
+            }                                                                                             \
+            const unsigned rowb_ = (unsigned)mm_ * (unsigned)((s_isb[s] ? p.chB : p.chA) * NT * 64);      \
+            rg[s] = s_isb[s] ? __builtin_amdgcn_raw_buffer_load_b128(rb_rsrc, ok_ ? rowb_ + s_goff[s] : OOB_OFF, 0, 0) \
+                             : __builtin_amdgcn_raw_buffer_load_b128(ra_rsrc, ok_ ? rowb_ + s_goff[s] : OOB_OFF, 0, 0); \
+        }                                                                                                 \
+    }
+#define MB_STORE(buf_)                                                                                    \
+    {                                                                                                     \
+        _Pragma("unroll") for (int s = 0; s < NP; ++s)                                                    \
+            *reinterpret_cast<u32x4*>(smem + (buf_) * STAGE + s_lds[s]) = rg[s];                          \
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // transposed-read addresses (see the 128 x 128 kernel): group g = lane>>4 covers columns 16*(g&1).. of a 32-wide tile
+    // and rows 8*(g>>1)..; lane 4q+pq of the group supplies row q, columns 4pq..4pq+3 (8 bytes)
+    const int g = lane >> 4, q4 = (lane & 15) >> 2, pq = lane & 3;
+    unsigned fa[4][2], fb[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int row = 8 * (g >> 1) + 4 * r + q4;
+        const unsigned swz = (unsigned)(((row & 3) << 2) | ((row >> 2) & 3));
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const int cha = ((wm * 128 + t * 32) >> 3) + 2 * (g & 1) + (pq >> 1);
+            fa[t][r] = 512u * row + 16u * ((unsigned)cha ^ swz) + 8u * (pq & 1);
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int chb = ((wn * 64 + t * 32) >> 3) + 2 * (g & 1) + (pq >> 1);
+            fb[t][r] = 512u * row + 16u * ((unsigned)chb ^ swz) + 8u * (pq & 1);
+        }
+    }
+
+    if (c_begin < c_end) {
+        MB_LOAD(c_begin)
+        MB_STORE(0)
+    }
+    __syncthreads();
+    for (int c = c_begin; c < c_end; c += KS) {
+        const int buf = ((c - c_begin) / KS) & 1;
+        if (c + KS < c_end) MB_LOAD(c + KS)
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const unsigned char* st = smem + buf * STAGE + ks * PIMG;
+            bf16x8 af[4][NT], bf[2][NT];
+            typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+#pragma unroll
+            for (int pl = 0; pl < NT; ++pl) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + pl * KS * PIMG + fa[t][0]));
+                    const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + pl * KS * PIMG + fa[t][1]));
+                    af[t][pl] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + (NT + pl) * KS * PIMG + fb[t][0]));
+                    const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + (NT + pl) * KS * PIMG + fb[t][1]));
+                    bf[t][pl] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if constexpr (NT == 3) {   // smallest terms first
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                    }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
+                }
+        }
+        if (c + KS < c_end) MB_STORE(buf ^ 1)
+        __syncthreads();
+    }
+#undef MB_LOAD
+#undef MB_STORE
+
+    float* out = p.slab + (size_t)split * p.Mi * p.Nj;
+    const int col0 = tj * 256 + wn * 64 + (lane & 31);
+    const int row0 = ti * 256 + wm * 128 + 4 * (lane >> 5);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = col0 + j * 32;
+        if (col >= p.Nj) continue;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                if (row < p.Mi) out[(size_t)row * p.Nj + col] = acc[i][j][r];
+            }
+    }
+}
+
+// one round of <= 256 workgroups: splits = 256 / tiles (>= 8 K-steps of 16 rows per split)
+MCPlan plan_mc_planes_big(int Mi, int Nj, int Mk) {
+    MCPlan pl;
+    if (Mk < 1) Mk = 1;
+    pl.big = 2;
+    const int tiles = ceil_div(Mi, 256) * ceil_div(Nj, 256);
+    const int total_chunks = ceil_div(Mk, 16);
+    int splits = 256 / tiles;
+    const char* env_s = getenv("PA2D_MCB_SPLITS");                          // tuning knob
+    if (env_s) splits = atoi(env_s);
+    const int max_splits = total_chunks / 8 > 0 ? total_chunks / 8 : 1;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    pl.chunks_per_split = ceil_div(total_chunks, splits);
+    pl.splits = ceil_div(total_chunks, pl.chunks_per_split);
+    pl.slab_floats = (size_t)pl.splits * Mi * Nj;
+    return pl;
+}
+
+// 0 = never, 1 = when the shape suits it (default), env PA2D_MC_BIG=off|auto
+bool mc_planes_big_applies(int C, int Cin, int Mk) {
+    const char* e = getenv("PA2D_MC_BIG");
+    if (e && e[0] == 'o') return false;
+    return (C % 16) == 0 && (Cin % 32) == 0 && 2 * C >= 256 && 9 * Cin >= 256 && Mk >= 16 * 8 * 4;
+}
+
+int launch_mc_planes_big(const void* PA, const void* PB, int C, int Cin, int Mk, int H, int W, float* slab,
+                         const MCPlan& pl, int NT, hipStream_t st) {
+    MCPlanesParams p;
+    p.PA = PA; p.chA = 2 * C / 32; p.PB = PB; p.chB = Cin / 32; p.slab = slab;
+    p.Mi = 2 * C; p.Nj = 9 * Cin; p.Mk = Mk; p.chunks_per_split = pl.chunks_per_split; p.splits = pl.splits;
+    p.H = H; p.W = W; p.Cin = Cin;
+    const unsigned long long ab = (unsigned long long)Mk * p.chA * NT * 64, bb = (unsigned long long)Mk * p.chB * NT * 64;
+    if (ab >= 0xFFFFFFF0ull || bb >= 0xFFFFFFF0ull) return PA2D_ERR_UNSUPPORTED;
+    p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
+    const int wgs = ceil_div(p.Mi, 256) * ceil_div(p.Nj, 256) * pl.splits;
+    const int per_xcd = ceil_div(wgs, 8);
+    const dim3 grid(per_xcd * 8);
+    static bool attr3 = false, attr1 = false;
+    if (NT == 3) {
+        const int smem = 2 * 2 * 3 * 1 * 8192;
+        if (!attr3) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mc_planes_big_kernel<3, 1>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            if (e != hipSuccess) return (int)e;
+            attr3 = true;
+        }
+        hipLaunchKernelGGL((gemm_mc_planes_big_kernel<3, 1>), grid, dim3(512), smem, st, p, per_xcd);
+    } else {
+        const int smem = 2 * 2 * 1 * 2 * 8192;
+        if (!attr1) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mc_planes_big_kernel<1, 2>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            if (e != hipSuccess) return (int)e;
+            attr1 = true;
+        }
+        hipLaunchKernelGGL((gemm_mc_planes_big_kernel<1, 2>), grid, dim3(512), smem, st, p, per_xcd);
+    }
+    PA2D_CHECK_LAUNCH();
+    return PA2D_OK;
+}

@@ -258,6 +258,7 @@ int launch_kc_split(KCParams& p, bool im2col, hipStream_t st) {
     } else if (!bf) {
         return PA2D_ERR_ARG;
     }
+    if (im2col && conv_halo_applies(p)) return launch_conv_halo(p, st);
     const dim3 grid(ceil_div(tiles_m, 8) * 8 * tiles_n);
     const int smem = 2 * (128 + 128) * (bf ? 80 : 208);
     static bool attr_done = false;
