@@ -50,10 +50,13 @@ PEAK_HBM_GBS = 8000.0             # HBM3E, MI355X_MICROARCH.md
 # MFMA terms per fp32 product -> fp32-equivalent peak = dense bf16 peak / 6.
 CONV_KERNELS = {ops.ENGINE_F32: ("gemm_kc_kernel<128,128,2,2,true,32>", PEAK_FP32_MFMA_TFLOPS),
                 ops.ENGINE_SPLIT: ("conv_halo_kernel<3>", round(PEAK_BF16_MFMA_TFLOPS / 6, 1)),
-                ops.ENGINE_BF16: ("gemm_kc_split_kernel<128,128,true,1,true>", PEAK_BF16_MFMA_TFLOPS)}
+                ops.ENGINE_BF16: ("conv_halo_kernel<1>", PEAK_BF16_MFMA_TFLOPS),
+                ops.ENGINE_BF16S: ("conv_halo_kernel<1,bf16>", PEAK_BF16_MFMA_TFLOPS)}
 ENGINE_LABEL = {ops.ENGINE_F32: "exact fp32 MFMA (all GEMMs)",
                 ops.ENGINE_SPLIT: "3xbf16-split/fp32-acc (conv), exact fp32 MFMA (linears)",
-                ops.ENGINE_BF16: "bf16 MFMA compute, f32 accumulate+storage (all GEMMs)"}
+                ops.ENGINE_BF16: "bf16 MFMA compute, f32 accumulate+storage (all GEMMs)",
+                ops.ENGINE_BF16S: "bf16 storage (activations, saved tensors, inter-kernel gradients) + bf16 MFMA, f32 "
+                                  "accumulate / master weights / statistics"}
 # algorithmic HBM bytes per launch of the slice-path kernels, in units of R*C*4 bytes (R = B*N rows):
 # scatter reads x_mid + v; de-slice reads x_mid, writes y; slice backward reads x_mid, fx_mid, dY, writes dX, dF
 HBM_KERNELS = {"slice_scatter": ("slice_scatter_kernel", 2.0), "deslice": ("deslice_kernel", 2.0),
@@ -278,6 +281,7 @@ class Ranks:
 def rooflines(ms_by_kind, engine, rows, C, traffic=None):
     """(roofline, roofline_hbm) dicts from the live HIP-event durations of one workload (rows = B*N)."""
     roof = hbm = None
+    esize = 2.0 if engine == ops.ENGINE_BF16S else 4.0        # bytes per stored activation element
     conv = ms_by_kind.get("conv") or []
     if conv:
         flops = 2.0 * rows * (9 * C) * (2 * C)
@@ -289,13 +293,13 @@ def rooflines(ms_by_kind, engine, rows, C, traffic=None):
                 "traffic_source": traffic["source"] if traffic else None,
                 "launches_timed": len(conv), "avg_launch_ms": round(avg, 4), "flops_per_launch": flops,
                 "peak_note": ("fp32-equivalent: dense bf16 MFMA peak / 6 terms" if engine == ops.ENGINE_SPLIT else
-                              ("dense bf16 MFMA" if engine == ops.ENGINE_BF16 else "fp32 MFMA"))}
+                              ("dense bf16 MFMA" if engine in (ops.ENGINE_BF16, ops.ENGINE_BF16S) else "fp32 MFMA"))}
     kernels, tot_b, tot_ms = [], 0.0, 0.0
     for kind, (kname, units) in HBM_KERNELS.items():
         ms = ms_by_kind.get(kind) or []
         if not ms:
             continue
-        nbytes = units * rows * C * 4.0
+        nbytes = units * rows * C * esize
         avg = float(np.mean(ms))
         gbs = nbytes / (avg * 1e-3) / 1e9
         kernels.append({"kernel": kname, "bytes_per_launch": nbytes, "avg_launch_ms": round(avg, 4),
@@ -307,7 +311,7 @@ def rooflines(ms_by_kind, engine, rows, C, traffic=None):
         hbm = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
                "note": "launch-weighted over the three slice-path kernels; algorithmic bytes per launch = "
-                       "2 / 2 / 5 x R*C*4 B (DESIGN.md §4)", "kernels": kernels}
+                       f"2 / 2 / 5 x R*C*{int(esize)} B (DESIGN.md §4)", "kernels": kernels}
     return roof, hbm
 
 
@@ -353,7 +357,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch-per-gpu", type=int, default=32)
-    ap.add_argument("--engine", default=None, choices=[None, "f32", "split", "bf16"],
+    ap.add_argument("--engine", default=None, choices=[None, "f32", "split", "bf16", "bf16s"],
                     help="GEMM engine of the measured model (default: PA2D_GEMM or the fp32-accurate split engine)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8, help="trajectories of the CPU protocol iteration (config C1: 8)")
@@ -372,6 +376,8 @@ def main():
     ap.add_argument("--roofline-steps", type=int, default=4,
                     help="timed steps (from the first) whose conv / slice kernels carry HIP events")
     ap.add_argument("--torch-optim", action="store_true", help="torch.optim.AdamW + torch rel-L2 instead of the fused kernels")
+    ap.add_argument("--bf16-grad-wire", action="store_true",
+                    help="all-reduce a bf16 copy of the gradient bucket (22.5 MB instead of 45 MB; accumulation stays fp32)")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: this process has not touched the GPU (no torch.cuda call,
@@ -391,7 +397,9 @@ def main():
         if args.torch_optim:
             o = torch.optim.AdamW(m.parameters(), lr=1e-3, weight_decay=1e-5)
             return o, ddp.FlatGradSync(m.parameters()), TestLoss(size_average=False)
-        o = FusedAdamW(m.parameters(), lr=1e-3, weight_decay=1e-5)    # fused multi-tensor AdamW + fused rel-L2 (§8(f)-1)
+        # fused multi-tensor AdamW + fused rel-L2 (§8(f)-1)
+        o = FusedAdamW(m.parameters(), lr=1e-3, weight_decay=1e-5,
+                       grad_comm_dtype=torch.bfloat16 if args.bf16_grad_wire else None)
         return o, o.sync, FusedTestLoss(size_average=False)
 
     opt, sync, loss_fn = make_optim(model)
@@ -436,7 +444,7 @@ def main():
     if os.path.exists(pmc) and B == 32 and not args.fold_time:
         try:      # PMC passes are a separate rocprofv3 run (they cannot ride in the timed region): static, labelled
             rec = json.load(open(pmc))
-            if rec.get("engine", "f32") == {0: "f32", 1: "split", 2: "bf16"}[engine]:
+            if rec.get("engine", "f32") == {0: "f32", 1: "split", 2: "bf16", 3: "bf16s"}[engine]:
                 traffic = {"bytes": rec.get("hbm_bytes_per_launch"),
                            "source": "profiles/conv_pmc_traffic.json (static: rocprofv3 --pmc passes of this kernel "
                                      "and launch shape, not measured in this run)"}
@@ -450,7 +458,8 @@ def main():
         "rccl_ranks": (dist.get_world_size() if world > 1 and rk.backend == "nccl" else (1 if world == 1 else 0)),
         "dist_backend": rk.backend, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1e3 * dt / args.steps, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if engine != ops.ENGINE_BF16 else "bf16 MFMA compute, f32 accumulate+storage", "data": "synthetic",
+        "dtype": {ops.ENGINE_F32: "f32", ops.ENGINE_SPLIT: "f32", ops.ENGINE_BF16: "bf16 MFMA compute, f32 accumulate+storage",
+                  ops.ENGINE_BF16S: "bf16"}[engine], "data": "synthetic",
         "config": {"workload": "exp_ns.py training iteration on NS 64x64 (10 teacher-forced Transolver calls + "
                                "backward + AdamW/OneCycleLR): Transolver_Structured_Mesh_2D 8 layers, C=256, 8 heads, "
                                f"M=64 slices, fp32, batch {B}/GPU (BASELINE configs[1])",

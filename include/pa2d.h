@@ -179,6 +179,55 @@ int pa2d_rel_l2_fwd(const float* pred, const float* y, float* dnorm, float* ynor
 int pa2d_rel_l2_bwd(const float* pred, const float* y, const float* dnorm, const float* ynorm,
                     const float* gout, float* dpred, int B, long long L, pa2d_stream_t stream);
 
+/* ==== bf16-STORAGE variants (BASELINE configs[2] "NS 64x64 bf16 ... DDP" and configs[4] "Darcy ... bf16"; the reference
+ * would reach these numerics with torch.autocast(bfloat16) around model/Transolver_Structured_Mesh_2D.py:202-220).
+ * Same stages, same argument order as the fp32 entry points above, but every ACTIVATION pointer (inputs, outputs,
+ * saved tensors, inter-kernel gradients: the `void*` arguments) holds bf16; parameters, biases, LayerNorm statistics,
+ * slice partial sums / norms, token tensors and every parameter gradient stay fp32; all accumulation is fp32.  GEMMs
+ * use ONE bf16 MFMA term (the arithmetic of PA2D_ENGINE_BF16; conv weight packs are made by pa2d_conv3x3x2_pack with
+ * PA2D_ENGINE_BF16).  ld* are in elements.  Dense layers need K % 32 == 0 (and N, K % 32 == 0 for the weight
+ * gradient, whose operands must be contiguous), the conv C % 32 == 0: otherwise PA2D_ERR_UNSUPPORTED. */
+int pa2d_layernorm_fwd_bf16(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                            int rows, int C, float eps, pa2d_stream_t stream);
+int pa2d_layernorm_bwd_bf16(const void* dy, const void* x, const float* mean, const float* rstd, const float* gamma,
+                            const void* dres, void* dx, float* dgamma, float* dbeta, void* ws, size_t ws_bytes,
+                            int rows, int C, int accumulate, pa2d_stream_t stream);
+int pa2d_gemm_bias_act_fwd_bf16(const void* x, long long ldx, const float* w, long long ldw, const float* bias,
+                                const void* res, long long ldres, void* y, long long ldy, void* pre, long long ldpre,
+                                int M, int N, int K, int act, pa2d_stream_t stream);
+int pa2d_gemm_bwd_data_bf16(const void* dy, long long lddy, const float* w, long long ldw, const void* pre,
+                            long long ldpre, int act, void* dx, long long lddx, float* wt_ws, int M, int N, int K,
+                            pa2d_stream_t stream);
+size_t pa2d_gemm_bwd_weight_workspace_bf16(int M, int N, int K);
+int pa2d_gemm_bwd_weight_bf16(const void* dy, long long lddy, const void* x, long long ldx, float* dw, float* db,
+                              void* ws, size_t ws_bytes, int M, int N, int K, int accumulate, pa2d_stream_t stream);
+size_t pa2d_conv3x3x2_workspace_bf16(int B, int H, int W, int C);       /* backward */
+size_t pa2d_conv3x3x2_fwd_workspace_bf16(int B, int H, int W, int C);   /* forward  */
+int pa2d_conv3x3x2_fwd_bf16(const void* xn, const float* wx, const float* bx, const float* wf, const float* bf,
+                            void* out, const void* prepacked, void* ws, size_t ws_bytes, int B, int H, int W, int C,
+                            pa2d_stream_t stream, void* ev_start, void* ev_stop);
+int pa2d_conv3x3x2_bwd_bf16(const void* dout, const void* xn, const float* wx, const float* wf, void* dxn, float* dwx,
+                            float* dbx, float* dwf, float* dbf, const void* prepacked, void* ws, size_t ws_bytes,
+                            int B, int H, int W, int C, int accumulate, pa2d_stream_t stream, void* ev_start,
+                            void* ev_stop);
+int pa2d_slice_scatter_bf16(const void* xm, long long ldx, const void* v, long long ldv, const float* ws,
+                            const float* bs, const float* temperature, float* spart, float* npart, int B, int N,
+                            int heads, int D, int M, int clamp_temperature, pa2d_stream_t stream, void* ev_start,
+                            void* ev_stop);
+int pa2d_deslice_fwd_bf16(const void* xm, long long ldx, const float* o, const float* ws, const float* bs,
+                          const float* temperature, void* y, long long ldy, int B, int N, int heads, int D, int M,
+                          int clamp_temperature, pa2d_stream_t stream, void* ev_start, void* ev_stop);
+int pa2d_slice_bwd_points_bf16(const void* xm, long long ldx, const void* fm, long long ldf, const void* dy,
+                               long long lddy, const float* ws, const float* bs, const float* temperature,
+                               const float* o, const float* ds, const float* dn, void* dxm, long long lddx,
+                               void* dfm, long long lddf, float* dws, float* dbs, float* dtemperature, void* ws_buf,
+                               size_t ws_bytes, int B, int N, int heads, int D, int M, int clamp_temperature,
+                               int accumulate, pa2d_stream_t stream, void* ev_start, void* ev_stop);
+int pa2d_head_fwd_bf16(const void* xn, const float* w, const float* b, float* y, int rows, int C, int out_dim,
+                       pa2d_stream_t stream);
+int pa2d_head_bwd_bf16(const float* dy, const void* xn, const float* w, void* dxn, float* dw, float* db, void* ws,
+                       size_t ws_bytes, int rows, int C, int out_dim, int accumulate, pa2d_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -57,6 +57,21 @@ SIGNATURES = {
     "pa2d_rel_l2_fwd": (_i, [_f, _f, _f, _f, _f, _i, _ll, _st]),
     "pa2d_rel_l2_bwd": (_i, [_f, _f, _f, _f, _f, _f, _i, _ll, _st]),
 }
+# bf16-storage variants: identical argument lists (activation pointers simply hold bf16); the GEMM / conv ones have no
+# `engine` argument (they ARE the bf16 engine)
+for _name in ("pa2d_layernorm_fwd", "pa2d_layernorm_bwd", "pa2d_slice_scatter", "pa2d_deslice_fwd", "pa2d_slice_bwd_points",
+              "pa2d_head_fwd", "pa2d_head_bwd"):
+    SIGNATURES[_name + "_bf16"] = SIGNATURES[_name]
+SIGNATURES.update({
+    "pa2d_gemm_bias_act_fwd_bf16": (_i, [_f, _ll, _f, _ll, _f, _f, _ll, _f, _ll, _f, _ll, _i, _i, _i, _i, _st]),
+    "pa2d_gemm_bwd_data_bf16": (_i, [_f, _ll, _f, _ll, _f, _ll, _i, _f, _ll, _f, _i, _i, _i, _st]),
+    "pa2d_gemm_bwd_weight_workspace_bf16": (_sz, [_i, _i, _i]),
+    "pa2d_gemm_bwd_weight_bf16": (_i, [_f, _ll, _f, _ll, _f, _f, _f, _sz, _i, _i, _i, _i, _st]),
+    "pa2d_conv3x3x2_workspace_bf16": (_sz, [_i, _i, _i, _i]),
+    "pa2d_conv3x3x2_fwd_workspace_bf16": (_sz, [_i, _i, _i, _i]),
+    "pa2d_conv3x3x2_fwd_bf16": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _i, _st, _st, _st]),
+    "pa2d_conv3x3x2_bwd_bf16": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _i, _i, _st, _st, _st]),
+})
 
 ERRORS = {1001: "PA2D_ERR_ARG (alignment/shape contract)", 1002: "PA2D_ERR_UNSUPPORTED (size outside kernel grid)",
           1003: "PA2D_ERR_WORKSPACE (workspace too small)"}

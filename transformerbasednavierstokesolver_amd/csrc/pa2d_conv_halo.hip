@@ -27,7 +27,7 @@ constexpr int TH = 8, TW = 32, BM = TH * TW, BN = 128;
 constexpr int HH = TH + 2, HWD = TW + 2, HROWS = HH * HWD;          // 10 x 34 = 340 halo pixels
 }
 
-template <int NT>
+template <int NT, typename TO = float>
 __global__ __launch_bounds__(512, 1) void conv_halo_kernel(const KCParams p, const int tiles_x, const int tiles_y,
                                                            const int nimg) {
     constexpr int PITCHB = NT * 64 + 16;
@@ -198,6 +198,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(const KCParams p, con
     // epilogue: out[pixel][col] = acc + bias.  Accumulator register r of lane l is pixel x0 + 4*(l>>5) + (r&3) + 8*(r>>2)
     // of image row y0 + wm*4 + i, column tile_n*128 + wn*64 + j*32 + (l & 31): 32 lanes write 128 contiguous bytes.
     const __amdgpu_buffer_rsrc_t rc = make_rsrc(p.C, p.c_bytes);
+    constexpr unsigned ES = Act<TO>::ES;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = tile_n * BN + wn * 64 + j * 32 + (lane & 31);
@@ -211,8 +212,8 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(const KCParams p, con
             for (int r = 0; r < 16; ++r) {
                 const int x = x0 + 4 * (lane >> 5) + (r & 3) + 8 * (r >> 2);
                 const bool ok = col_ok && y < p.H && x < p.W;
-                buf_store1(rc, ok ? ((rowbase + (unsigned)x) * (unsigned)p.ldc + (unsigned)col) * 4u : OOB_OFF,
-                           acc[i][j][r] + bv);
+                Act<TO>::bst1(rc, ok ? ((rowbase + (unsigned)x) * (unsigned)p.ldc + (unsigned)col) * ES : OOB_OFF,
+                              acc[i][j][r] + bv);
             }
         }
     }
@@ -249,6 +250,15 @@ int launch_conv_halo(const KCParams& p, hipStream_t st) {
             attr3 = true;
         }
         hipLaunchKernelGGL((conv_halo_kernel<3>), grid, dim3(512), smem, st, p, tiles_x, tiles_y, nimg);
+    } else if (p.io_bf16) {
+        static bool attr1b = false;
+        if (!attr1b) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<1, bf16_t>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            if (e != hipSuccess) return (int)e;
+            attr1b = true;
+        }
+        hipLaunchKernelGGL((conv_halo_kernel<1, bf16_t>), grid, dim3(512), smem, st, p, tiles_x, tiles_y, nimg);
     } else {
         if (!attr1) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<1>),

@@ -48,9 +48,10 @@ static int launch_kc(const KCParams& p_in, bool im2col, hipStream_t st, hipEvent
         if (ab >= 0xFFFFFFF0ull || bb >= 0xFFFFFFF0ull) return PA2D_ERR_UNSUPPORTED;
         p.a_bytes = (unsigned)ab;
         p.b_bytes = (unsigned)bb;
-        const unsigned long long cb = ((unsigned long long)(p.M - 1) * p.ldc + p.N) * 4ull;
-        const unsigned long long rb = p.res ? ((unsigned long long)(p.M - 1) * p.ldres + p.N) * 4ull : 0ull;
-        const unsigned long long xb = p.aux ? ((unsigned long long)(p.M - 1) * p.ldaux + p.N) * 4ull : 0ull;
+        const unsigned long long es = p.io_bf16 ? 2ull : 4ull;      // storage size of C / res / aux
+        const unsigned long long cb = ((unsigned long long)(p.M - 1) * p.ldc + p.N) * es;
+        const unsigned long long rb = p.res ? ((unsigned long long)(p.M - 1) * p.ldres + p.N) * es : 0ull;
+        const unsigned long long xb = p.aux ? ((unsigned long long)(p.M - 1) * p.ldaux + p.N) * es : 0ull;
         if (cb >= 0xFFFFFFF0ull || rb >= 0xFFFFFFF0ull || xb >= 0xFFFFFFF0ull) return PA2D_ERR_UNSUPPORTED;
         p.c_bytes = (unsigned)cb; p.res_bytes = (unsigned)rb; p.aux_bytes = (unsigned)xb;
     }
@@ -59,7 +60,7 @@ static int launch_kc(const KCParams& p_in, bool im2col, hipStream_t st, hipEvent
     if (im2col && (p.epi != 0 || p.res)) return PA2D_ERR_ARG;      // conv kernels carry the bias-only epilogue
     if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return PA2D_ERR_ARG;
     int rc;
-    if (use_split(p.engine, p.N, im2col, p.Cin)) rc = launch_kc_split(p, im2col, st);
+    if (p.io_bf16 || use_split(p.engine, p.N, im2col, p.Cin)) rc = launch_kc_split(p, im2col, st);
     else rc = launch_kc_f32(p, im2col, kc_tile(p.M, p.N, im2col, p.Cin), st);
     if (rc) return rc;
     if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return PA2D_ERR_ARG;
@@ -321,6 +322,138 @@ int pa2d_conv3x3x2_bwd(const float* dout, const float* xn, const float* wx, cons
     rc = launch_reduce(scratch, pl.splits, (long long)2 * C * 9 * C, dwx, dwf, 1, C, C, st, accumulate);
     if (rc) return rc;
     return launch_colsum(dout, 2 * C, M, 2 * C, dbx, scratch, st, dbf, C, accumulate);
+}
+
+
+// =============================================================================================
+// bf16-STORAGE variants (BASELINE configs[2] / [4] as stated): activations, saved tensors and inter-kernel gradients are
+// bf16 in HBM; weights, biases and every parameter gradient stay fp32; all products are ONE bf16 MFMA term with fp32
+// accumulation (the arithmetic of PA2D_ENGINE_BF16, minus its fp32 round trips: a bf16 tensor IS the 1-plane operand
+// image the bf16 kernels stage, so the activation pre-passes disappear).  ld* are in ELEMENTS.  Requires K % 32 == 0
+// for the dense layers and C % 32 == 0 for the conv (PA2D_ERR_UNSUPPORTED otherwise, never a silent fallback).
+
+int pa2d_gemm_bias_act_fwd_bf16(const void* x, long long ldx, const float* w, long long ldw, const float* bias,
+                                const void* res, long long ldres, void* y, long long ldy, void* pre, long long ldpre,
+                                int M, int N, int K, int act, hipStream_t st) {
+    KCParams p = {};
+    p.engine = 2; p.io_bf16 = 1; p.apre = 1;
+    p.A = (const float*)x; p.lda = ldx; p.B = w; p.ldb = ldw; p.C = (float*)y; p.ldc = ldy; p.bias = bias;
+    p.res = (const float*)res; p.ldres = ldres; p.aux = (float*)pre; p.ldaux = ldpre; p.M = M; p.N = N; p.K = K; p.act = act;
+    p.epi = (act != ACT_NONE ? EPI_ACT : 0) | (pre ? EPI_STORE_PRE : 0);
+    return launch_kc(p, false, st);
+}
+
+// dx[M,K] = (dy[M,N] . w[N,K]) * act'(pre[M,K]); dy, pre, dx bf16; w fp32; wt_ws: K*N floats (transposed weight)
+int pa2d_gemm_bwd_data_bf16(const void* dy, long long lddy, const float* w, long long ldw, const void* pre,
+                            long long ldpre, int act, void* dx, long long lddx, float* wt_ws, int M, int N, int K,
+                            hipStream_t st) {
+    if (ldw != K) return PA2D_ERR_ARG;
+    if (N & 3) return PA2D_ERR_ARG;
+    if (M <= 0) return PA2D_OK;
+    int rc = launch_repack(w, nullptr, wt_ws, 0, N, K, 0, 0, st);
+    if (rc) return rc;
+    KCParams p = {};
+    p.engine = 2; p.io_bf16 = 1; p.apre = 1;
+    p.A = (const float*)dy; p.lda = lddy; p.B = wt_ws; p.ldb = N; p.C = (float*)dx; p.ldc = lddx; p.M = M; p.N = K; p.K = N;
+    p.aux = (float*)const_cast<void*>(pre); p.ldaux = ldpre; p.act = act;
+    p.epi = (pre && act != ACT_NONE) ? EPI_MUL_DACT : 0;
+    return launch_kc(p, false, st);
+}
+
+size_t pa2d_gemm_bwd_weight_workspace_bf16(int M, int N, int K) {
+    const MCPlan pl = plan_mc_planes_big(N, K, M);
+    size_t a = pl.slab_floats, b = (size_t)colsum_blocks(M) * N;
+    return (a > b ? a : b) * sizeof(float);
+}
+
+// dw[N,K] (+)= dy[M,N]^T . x[M,K] (fp32), db[N] (+)= column sums of dy; dy, x bf16 and CONTIGUOUS (lddy == N, ldx == K)
+int pa2d_gemm_bwd_weight_bf16(const void* dy, long long lddy, const void* x, long long ldx, float* dw, float* db,
+                              void* ws, size_t ws_bytes, int M, int N, int K, int accumulate, hipStream_t st) {
+    if (lddy != N || ldx != K) return PA2D_ERR_ARG;
+    if ((N & 31) || (K & 31)) return PA2D_ERR_UNSUPPORTED;
+    if (M <= 0) {
+        if (accumulate) return PA2D_OK;
+        const int rz = pa2d_zero(dw, sizeof(float) * N * K, st);
+        return rz ? rz : pa2d_zero(db, sizeof(float) * N, st);
+    }
+    if (ws_bytes < pa2d_gemm_bwd_weight_workspace_bf16(M, N, K)) return PA2D_ERR_WORKSPACE;
+    const MCPlan pl = plan_mc_planes_big(N, K, M);
+    int rc = launch_mc_planes_big_raw(dy, N, x, K, 1, M, 1, 1, (float*)ws, pl, 1, st);
+    if (rc) return rc;
+    rc = launch_reduce((const float*)ws, pl.splits, (long long)N * K, dw, nullptr, 0, 0, 0, st, accumulate);
+    if (rc) return rc;
+    if (db) rc = launch_colsum_bf16(dy, lddy, M, N, db, (float*)ws, st, nullptr, 0, accumulate);
+    return rc;
+}
+
+size_t pa2d_conv3x3x2_fwd_workspace_bf16(int B, int H, int W, int C) {
+    (void)B; (void)H; (void)W;
+    return pa2d_conv3x3x2_pack_bytes(C);
+}
+size_t pa2d_conv3x3x2_workspace_bf16(int B, int H, int W, int C) {
+    const MCPlan pl = plan_mc_planes_big(2 * C, 9 * C, B * H * W);
+    size_t sl = pl.slab_floats, cs = (size_t)colsum_blocks(B * H * W) * 2 * C;
+    return pa2d_conv3x3x2_pack_bytes(C) + (sl > cs ? sl : cs) * sizeof(float);
+}
+
+// xn [B*H*W, C] bf16 -> out [B*H*W, 2C] bf16; weights / biases fp32 (prepacked: pa2d_conv3x3x2_pack with PA2D_ENGINE_BF16)
+int pa2d_conv3x3x2_fwd_bf16(const void* xn, const float* wx, const float* bx, const float* wf, const float* bf, void* out,
+                            const void* prepacked, void* ws, size_t ws_bytes, int B, int H, int W, int C, hipStream_t st,
+                            hipEvent_t ev_start, hipEvent_t ev_stop) {
+    if (C & 31) return PA2D_ERR_UNSUPPORTED;
+    if (B <= 0) return PA2D_OK;
+    if (ws_bytes < pa2d_conv3x3x2_fwd_workspace_bf16(B, H, W, C)) return PA2D_ERR_WORKSPACE;
+    const float* pack = (const float*)prepacked;
+    if (!pack) {
+        const int rc = launch_repack_split(wx, wf, ws, 0, 1, C, C, st);
+        if (rc) return rc;
+        pack = (const float*)ws;
+    }
+    KCParams p = {};
+    p.engine = 2; p.io_bf16 = 1; p.apre = 1;
+    p.A = (const float*)xn; p.lda = C; p.B = pack; p.ldb = 9 * C; p.C = (float*)out; p.ldc = 2 * C;
+    p.bias = bx; p.bias2 = bf; p.bias_split = C;
+    p.M = B * H * W; p.N = 2 * C; p.K = 9 * C; p.H = H; p.W = W; p.Cin = C;
+    return launch_kc(p, true, st, ev_start, ev_stop);
+}
+
+// dout [B*H*W, 2C] bf16, xn bf16 -> dxn bf16 (may be NULL); dwx/dwf/dbx/dbf fp32 ((+)= per accumulate)
+int pa2d_conv3x3x2_bwd_bf16(const void* dout, const void* xn, const float* wx, const float* wf, void* dxn, float* dwx,
+                            float* dbx, float* dwf, float* dbf, const void* prepacked, void* ws, size_t ws_bytes, int B,
+                            int H, int W, int C, int accumulate, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    if (C & 31) return PA2D_ERR_UNSUPPORTED;
+    if (B <= 0) {
+        if (accumulate) return PA2D_OK;
+        const size_t wb = sizeof(float) * (size_t)C * C * 9, bb = sizeof(float) * C;
+        int rz = pa2d_zero(dwx, wb, st);
+        if (!rz) rz = pa2d_zero(dwf, wb, st);
+        if (!rz) rz = pa2d_zero(dbx, bb, st);
+        return rz ? rz : pa2d_zero(dbf, bb, st);
+    }
+    if (ws_bytes < pa2d_conv3x3x2_workspace_bf16(B, H, W, C)) return PA2D_ERR_WORKSPACE;
+    float* scratch = (float*)((char*)ws + pa2d_conv3x3x2_pack_bytes(C));
+    const int M = B * H * W;
+    int rc;
+    if (dxn) {
+        const float* pack = (const float*)prepacked;
+        if (!pack) {
+            rc = launch_repack_split(wx, wf, ws, 1, 1, C, C, st);
+            if (rc) return rc;
+            pack = (const float*)ws;
+        }
+        KCParams p = {};
+        p.engine = 2; p.io_bf16 = 1; p.apre = 1;
+        p.A = (const float*)dout; p.lda = 2 * C; p.B = pack; p.ldb = 9 * 2 * C; p.C = (float*)dxn; p.ldc = C;
+        p.M = M; p.N = C; p.K = 9 * 2 * C; p.H = H; p.W = W; p.Cin = 2 * C;
+        rc = launch_kc(p, true, st, ev_start, ev_stop);
+        if (rc) return rc;
+    }
+    const MCPlan pl = plan_mc_planes_big(2 * C, 9 * C, M);
+    rc = launch_mc_planes_big_raw(dout, 2 * C, xn, C, 9, M, H, W, scratch, pl, 1, st);
+    if (rc) return rc;
+    rc = launch_reduce(scratch, pl.splits, (long long)2 * C * 9 * C, dwx, dwf, 1, C, C, st, accumulate);
+    if (rc) return rc;
+    return launch_colsum_bf16(dout, 2 * C, M, 2 * C, dbx, scratch, st, dbf, C, accumulate);
 }
 
 }  // extern "C"

@@ -25,6 +25,8 @@ struct KCParams {
     unsigned c_bytes, res_bytes, aux_bytes;
     int apre;   // split engine: A already holds the NT bf16 planes of every 32-channel chunk (split_planes_kernel)
     int engine; // PA2D_ENGINE_* of this call (explicit per call: the library keeps no engine state)
+    int io_bf16; // bf16-storage entry points: A (row-major [M][K] or the NHWC image), C, res and aux hold bf16; lda / ldc /
+                 // ldres / ldaux stay in ELEMENTS; a bf16 A is read as pre-made 1-plane "planes" (apre = 1)
 };
 
 __device__ __forceinline__ float gelu_f(float x) { return gelu_exact(x); }
@@ -33,10 +35,11 @@ __device__ __forceinline__ float dgelu_f(float x) { return dgelu_exact(x); }
 // Branch-free epilogue of one 32x32 accumulator tile.  Ragged rows / columns are masked by the buffer
 // range check (masked lanes get offset OOB_OFF: loads return 0, stores are dropped); all residual /
 // pre-activation loads of the tile are issued before the first use.  ACT_ID < 0: runtime p.act.
-template <bool HAS_RES, bool STORE_PRE, bool ACT, bool DACT, int ACT_ID>
+template <bool HAS_RES, bool STORE_PRE, bool ACT, bool DACT, int ACT_ID, typename TO = float>
 __device__ __forceinline__ void kc_epilogue_tile(const KCParams& p, const f32x16& acc, int row_base, int col,
                                                  __amdgpu_buffer_rsrc_t rc, __amdgpu_buffer_rsrc_t rres,
                                                  __amdgpu_buffer_rsrc_t raux) {
+    constexpr unsigned ES = Act<TO>::ES;
     const bool col_ok = col < p.N;
     const float bv = (p.bias && col_ok) ? (col < p.bias_split ? p.bias[col] : p.bias2[col - p.bias_split]) : 0.f;
     unsigned offc[16];
@@ -45,25 +48,25 @@ __device__ __forceinline__ void kc_epilogue_tile(const KCParams& p, const f32x16
     for (int r = 0; r < 16; ++r) {
         const int row = row_base + (r & 3) + 8 * (r >> 2);
         const bool ok = col_ok && row < p.M;
-        offc[r] = ok ? ((unsigned)row * (unsigned)p.ldc + (unsigned)col) * 4u : OOB_OFF;
-        if (HAS_RES) rv[r] = buf_load1(rres, ok ? ((unsigned)row * (unsigned)p.ldres + (unsigned)col) * 4u : OOB_OFF);
-        if (DACT) av[r] = buf_load1(raux, ok ? ((unsigned)row * (unsigned)p.ldaux + (unsigned)col) * 4u : OOB_OFF);
+        offc[r] = ok ? ((unsigned)row * (unsigned)p.ldc + (unsigned)col) * ES : OOB_OFF;
+        if (HAS_RES) rv[r] = Act<TO>::bld1(rres, ok ? ((unsigned)row * (unsigned)p.ldres + (unsigned)col) * ES : OOB_OFF);
+        if (DACT) av[r] = Act<TO>::bld1(raux, ok ? ((unsigned)row * (unsigned)p.ldaux + (unsigned)col) * ES : OOB_OFF);
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = row_base + (r & 3) + 8 * (r >> 2);
         float v = acc[r] + bv;
         if (STORE_PRE)
-            buf_store1(raux, offc[r] != OOB_OFF ? ((unsigned)row * (unsigned)p.ldaux + (unsigned)col) * 4u : OOB_OFF, v);
+            Act<TO>::bst1(raux, offc[r] != OOB_OFF ? ((unsigned)row * (unsigned)p.ldaux + (unsigned)col) * ES : OOB_OFF, v);
         if (ACT) v = ACT_ID == ACT_GELU ? gelu_f(v) : act_fwd(p.act, v);
         if (DACT) v *= ACT_ID == ACT_GELU ? dgelu_f(av[r]) : act_bwd(p.act, av[r]);
         if (HAS_RES) v += rv[r];
-        buf_store1(rc, offc[r], v);
+        Act<TO>::bst1(rc, offc[r], v);
     }
 }
 
 // BIAS_ONLY: the conv implicit GEMMs only ever store acc (+ bias): one variant instead of nine (compile time)
-template <int TM, int TN, bool BIAS_ONLY = false>
+template <int TM, int TN, bool BIAS_ONLY = false, typename TO = float>
 __device__ __forceinline__ void kc_epilogue(const KCParams& p, f32x16 (&acc)[TM][TN], int row0, int col0) {
     const __amdgpu_buffer_rsrc_t rc = make_rsrc(p.C, p.c_bytes);
     const __amdgpu_buffer_rsrc_t rres = make_rsrc(p.res ? p.res : p.C, p.res ? p.res_bytes : 0u);
@@ -72,7 +75,7 @@ __device__ __forceinline__ void kc_epilogue(const KCParams& p, f32x16 (&acc)[TM]
     const bool gelu = p.act == ACT_GELU;
 #define KC_EPI(HR, SP, AC, DA, ID)                                                                     \
     _Pragma("unroll") for (int j = 0; j < TN; ++j) _Pragma("unroll") for (int i = 0; i < TM; ++i)      \
-        kc_epilogue_tile<HR, SP, AC, DA, ID>(p, acc[i][j], row0 + i * 32, col0 + j * 32, rc, rres, raux);
+        kc_epilogue_tile<HR, SP, AC, DA, ID, TO>(p, acc[i][j], row0 + i * 32, col0 + j * 32, rc, rres, raux);
     if constexpr (BIAS_ONLY) {
         KC_EPI(false, false, false, false, 0)
     } else if (p.epi == 0) {
@@ -149,6 +152,10 @@ bool mc_planes_big_applies(int C, int Cin, int Mk);
 MCPlan plan_mc_planes_big(int Mi, int Nj, int Mk);
 int launch_mc_planes_big(const void* PA, const void* PB, int C, int Cin, int Mk, int H, int W, float* slab,
                          const MCPlan& pl, int NT, hipStream_t st);
+int launch_mc_planes_big_raw(const void* PA, int Mi, const void* PB, int Cin, int taps, int Mk, int H, int W, float* slab,
+                             const MCPlan& pl, int NT, hipStream_t st);
 int colsum_blocks(int M);
+int launch_colsum_bf16(const void* X, long long ld, int M, int N, float* out, float* partial, hipStream_t st,
+                       float* out2 = nullptr, int split = 0, int accumulate = 0);
 int launch_colsum(const float* X, long long ld, int M, int N, float* out, float* partial, hipStream_t st,
                   float* out2 = nullptr, int split = 0, int accumulate = 0);

@@ -373,7 +373,8 @@ int pa2d_launch_reduce_segs(const float* slab, int nslab, long long count, const
 
 // ---------------------------------------------------------------------------------------------
 // column sums (bias gradients): partial[blk][n] over row blocks, then reduce_slabs.
-__global__ void colsum_partial_kernel(const float* __restrict__ X, long long ld, int M, int N, int rows_per_block,
+template <typename T>
+__global__ void colsum_partial_kernel(const T* __restrict__ X, long long ld, int M, int N, int rows_per_block,
                                       float* __restrict__ partial) {
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(M, r0 + rows_per_block);
@@ -381,12 +382,12 @@ __global__ void colsum_partial_kernel(const float* __restrict__ X, long long ld,
         float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
         int r = r0;
         for (; r + 3 < r1; r += 4) {
-            s0 += X[(size_t)r * ld + c];
-            s1 += X[(size_t)(r + 1) * ld + c];
-            s2 += X[(size_t)(r + 2) * ld + c];
-            s3 += X[(size_t)(r + 3) * ld + c];
+            s0 += Act<T>::ld1(&X[(size_t)r * ld + c]);
+            s1 += Act<T>::ld1(&X[(size_t)(r + 1) * ld + c]);
+            s2 += Act<T>::ld1(&X[(size_t)(r + 2) * ld + c]);
+            s3 += Act<T>::ld1(&X[(size_t)(r + 3) * ld + c]);
         }
-        for (; r < r1; ++r) s0 += X[(size_t)r * ld + c];
+        for (; r < r1; ++r) s0 += Act<T>::ld1(&X[(size_t)r * ld + c]);
         partial[(size_t)blockIdx.x * N + c] = (s0 + s1) + (s2 + s3);
     }
 }
@@ -398,7 +399,15 @@ int launch_colsum(const float* X, long long ld, int M, int N, float* out, float*
                          float* out2, int split, int accumulate) {
     const int nb = colsum_blocks(M);
     const int rpb = ceil_div(M, nb);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, st, X, ld, M, N, rpb, partial);
+    hipLaunchKernelGGL((colsum_partial_kernel<float>), dim3(nb), dim3(256), 0, st, X, ld, M, N, rpb, partial);
+    PA2D_CHECK_LAUNCH();
+    return launch_reduce(partial, nb, N, out, out2, out2 ? 2 : 0, split, 0, st, accumulate);
+}
+int launch_colsum_bf16(const void* X, long long ld, int M, int N, float* out, float* partial, hipStream_t st,
+                       float* out2, int split, int accumulate) {
+    const int nb = colsum_blocks(M);
+    const int rpb = ceil_div(M, nb);
+    hipLaunchKernelGGL((colsum_partial_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)X, ld, M, N, rpb, partial);
     PA2D_CHECK_LAUNCH();
     return launch_reduce(partial, nb, N, out, out2, out2 ? 2 : 0, split, 0, st, accumulate);
 }

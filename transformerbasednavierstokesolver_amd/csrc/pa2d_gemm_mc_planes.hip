@@ -19,6 +19,7 @@ struct MCPlanesParams {
     float* slab;
     int Mi, Nj, Mk, chunks_per_split, splits, H, W, Cin;
     unsigned a_bytes, b_bytes;
+    int taps;                     // 9: columns are (tap, input channel) of a 3x3 conv; 1: plain dW = A^T . B (big kernel only)
 };
 
 __device__ __forceinline__ unsigned img_off(int row, int ch) {       // byte offset inside one 4 KB plane image
@@ -197,7 +198,7 @@ int launch_mc_planes(const void* PA, const void* PB, int C, int Cin, int Mk, int
     MCPlanesParams p;
     p.PA = PA; p.chA = 2 * C / 32; p.PB = PB; p.chB = Cin / 32; p.slab = slab;
     p.Mi = 2 * C; p.Nj = 9 * Cin; p.Mk = Mk; p.chunks_per_split = pl.chunks_per_split; p.splits = pl.splits;
-    p.H = H; p.W = W; p.Cin = Cin;
+    p.H = H; p.W = W; p.Cin = Cin; p.taps = 9;
     const unsigned long long ab = (unsigned long long)Mk * p.chA * NT * 64, bb = (unsigned long long)Mk * p.chB * NT * 64;
     if (ab >= 0xFFFFFFF0ull || bb >= 0xFFFFFFF0ull) return PA2D_ERR_UNSUPPORTED;
     p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
@@ -236,7 +237,7 @@ __global__ __launch_bounds__(512, 1) void gemm_mc_planes_big_kernel(const MCPlan
     const int total_chunks = (p.Mk + 15) / 16;
     const int c_begin = split * p.chunks_per_split;
     const int c_end = min(total_chunks, c_begin + p.chunks_per_split);
-    const int HW = p.H * p.W;
+    const int HW = p.taps == 1 ? 1 : p.H * p.W;
 
     const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.PA), 0, p.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.PB), 0, p.b_bytes, 0x00020000);
@@ -259,8 +260,8 @@ __global__ __launch_bounds__(512, 1) void gemm_mc_planes_big_kernel(const MCPlan
         bool colok;
         if (op) {          // X: column group c of this tile = columns jc..jc+31 = one tap, one 32-channel chunk
             const int jc = tj * 256 + c * 32;
-            const int tap = jc / p.Cin;
-            chunk = (jc - tap * p.Cin) >> 5;
+            const int tap = p.taps == 1 ? 4 : jc / p.Cin;              // plain GEMM: the centre tap (no shift)
+            chunk = p.taps == 1 ? (jc >> 5) : ((jc - tap * p.Cin) >> 5);
             colok = jc < p.Nj;
             s_dy[s] = tap / 3 - 1;
             s_dx[s] = tap - (tap / 3) * 3 - 1;
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(512, 1) void gemm_mc_planes_big_kernel(const MCPlan
             const int m_ = m0_ + s_row[s];                                                                \
             bool ok_ = s_goff[s] != OOB_OFF && m_ < p.Mk && (KS == 1 || (c_) + (s_row[s] >> 4) < c_end);  \
             int mm_ = m_;                                                                                 \
-            if (s_isb[s]) {                                                                               \
+            if (s_isb[s] && p.taps != 1) {                                                                \
                 const int n_ = m_ % HW;                                                                   \
                 const int y_ = n_ / p.W, x_ = n_ - y_ * p.W;                                              \
                 ok_ = ok_ && (unsigned)(y_ + s_dy[s]) < (unsigned)p.H && (unsigned)(x_ + s_dx[s]) < (unsigned)p.W; \
@@ -421,10 +422,18 @@ bool mc_planes_big_applies(int C, int Cin, int Mk) {
 
 int launch_mc_planes_big(const void* PA, const void* PB, int C, int Cin, int Mk, int H, int W, float* slab,
                          const MCPlan& pl, int NT, hipStream_t st) {
+    return launch_mc_planes_big_raw(PA, 2 * C, PB, Cin, 9, Mk, H, W, slab, pl, NT, st);
+}
+
+// General form: slab[split][Mi][Nj] += A[m][Mi]^T . B[m (shifted by tap)][Cin]; taps = 9 -> Nj = 9*Cin (3x3 conv weight
+// gradient), taps = 1 -> Nj = Cin (plain dW = dY^T . X).  A, B: NT-plane images with Mi / Cin multiples of 32.
+int launch_mc_planes_big_raw(const void* PA, int Mi, const void* PB, int Cin, int taps, int Mk, int H, int W, float* slab,
+                             const MCPlan& pl, int NT, hipStream_t st) {
+    if ((Mi & 31) || (Cin & 31) || (taps != 1 && taps != 9)) return PA2D_ERR_UNSUPPORTED;
     MCPlanesParams p;
-    p.PA = PA; p.chA = 2 * C / 32; p.PB = PB; p.chB = Cin / 32; p.slab = slab;
-    p.Mi = 2 * C; p.Nj = 9 * Cin; p.Mk = Mk; p.chunks_per_split = pl.chunks_per_split; p.splits = pl.splits;
-    p.H = H; p.W = W; p.Cin = Cin;
+    p.PA = PA; p.chA = Mi / 32; p.PB = PB; p.chB = Cin / 32; p.slab = slab;
+    p.Mi = Mi; p.Nj = taps * Cin; p.Mk = Mk; p.chunks_per_split = pl.chunks_per_split; p.splits = pl.splits;
+    p.H = H; p.W = W; p.Cin = Cin; p.taps = taps;
     const unsigned long long ab = (unsigned long long)Mk * p.chA * NT * 64, bb = (unsigned long long)Mk * p.chB * NT * 64;
     if (ab >= 0xFFFFFFF0ull || bb >= 0xFFFFFFF0ull) return PA2D_ERR_UNSUPPORTED;
     p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;

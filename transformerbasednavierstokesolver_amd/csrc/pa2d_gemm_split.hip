@@ -25,7 +25,9 @@
 // APRE: the A operand arrives pre-split as well ([pixel][32-channel chunk][plane][32] bf16, made once per tensor by
 // split_planes_kernel), so BOTH tiles are staged with 16-byte copies and the producers do no conversion work:
 // each activation element is converted once instead of once per (tap, column tile) = 36 times.
-template <int BM, int BN, bool IM2COL, int NT, bool APRE = false>
+// TO: storage type of C / res / aux (float, or bf16 for the bf16-storage entry points).  APRE without IM2COL: A is a
+// row-major bf16 matrix [M][K] (K % 32 == 0), i.e. already the 1-plane image of every 32-wide K-step.
+template <int BM, int BN, bool IM2COL, int NT, bool APRE = false, typename TO = float>
 __global__ __launch_bounds__(512, (BM + BN > 256) ? 1 : 2) void gemm_kc_split_kernel(const KCParams p) {
     constexpr int BK = 32, PITCHB = NT * 64 + 16;        // bytes per LDS row (NT planes x 64 B + 16): 208 / 80
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
@@ -64,9 +66,10 @@ __global__ __launch_bounds__(512, (BM + BN > 256) ? 1 : 2) void gemm_kc_split_ke
         for (int s = 0; s < AP_IT; ++s) {
             const int q = ptid + 256 * s, row = q / PIECES, piece = q - row * PIECES;
             const int gm = tile_m * BM + row;
-            ap_off[s] = (APRE && gm < p.M) ? ((unsigned)gm * (unsigned)(nch_in * PIECES) + piece) * 16u : OOB_OFF;
+            ap_off[s] = (APRE && gm < p.M) ? (IM2COL ? ((unsigned)gm * (unsigned)(nch_in * PIECES) + piece) * 16u
+                                                     : (unsigned)gm * (unsigned)p.lda * 2u + piece * 16u) : OOB_OFF;
             ap_lds[s] = row * PITCHB + piece * 16;
-            const int n = APRE ? gm % (p.H * p.W) : 0;
+            const int n = (APRE && IM2COL) ? gm % (p.H * p.W) : 0;
             ap_y[s] = n / p.W;
             ap_x[s] = n - ap_y[s] * p.W;
         }
@@ -101,7 +104,11 @@ __global__ __launch_bounds__(512, (BM + BN > 256) ? 1 : 2) void gemm_kc_split_ke
     {                                                                                                  \
         const int k0_ = (kc_) * BK;                                                                    \
         const bool kin_ = k0_ + lq * 4 < p.K;                                                          \
-        if (APRE) {                                                                                    \
+        if (APRE && !IM2COL) {                                                                         \
+            _Pragma("unroll") for (int s = 0; s < AP_IT; ++s)                                          \
+                RQ[s] = __builtin_amdgcn_raw_buffer_load_b128(                                         \
+                    ra_rsrc, ap_off[s] != OOB_OFF ? ap_off[s] + (unsigned)(kc_) * (PIECES * 16u) : OOB_OFF, 0, 0); \
+        } else if (APRE) {                                                                             \
             const int cic_ = (kc_) / 9, tap_ = (kc_) - cic_ * 9;                                       \
             const int dy_ = tap_ / 3 - 1, dx_ = tap_ - (tap_ / 3) * 3 - 1;                             \
             const int sh_ = ((dy_ * p.W + dx_) * nch_in + cic_) * (PIECES * 16);                       \
@@ -240,7 +247,7 @@ __global__ __launch_bounds__(512, (BM + BN > 256) ? 1 : 2) void gemm_kc_split_ke
         __syncthreads();
     }
 
-    kc_epilogue<TM, TN, IM2COL>(p, acc, tile_m * BM + wm * WM + 4 * (lane >> 5), tile_n * BN + wn * WN + (lane & 31));
+    kc_epilogue<TM, TN, IM2COL, TO>(p, acc, tile_m * BM + wm * WM + 4 * (lane >> 5), tile_n * BN + wn * WN + (lane & 31));
 }
 
 // Variants in use: conv (im2col) GEMMs always take pre-split activation planes (NT = 3: fp32-accurate split,
@@ -257,6 +264,20 @@ int launch_kc_split(KCParams& p, bool im2col, hipStream_t st) {
         p.b_bytes = (unsigned)((size_t)p.N * (p.K / 32) * planes * 64);
     } else if (!bf) {
         return PA2D_ERR_ARG;
+    }
+    if (p.io_bf16) {          // bf16-storage entry points: A is the bf16 tensor itself, outputs are bf16
+        if (!bf || (!im2col && (p.K % 32) != 0)) return PA2D_ERR_UNSUPPORTED;
+        if (!im2col) {
+            const unsigned long long ab = ((unsigned long long)(p.M - 1) * p.lda + p.K) * 2ull;
+            if (ab >= 0xFFFFFFF0ull) return PA2D_ERR_UNSUPPORTED;
+            p.a_bytes = (unsigned)ab;
+        }
+        if (im2col && conv_halo_applies(p)) return launch_conv_halo(p, st);
+        const dim3 g16(ceil_div(tiles_m, 8) * 8 * tiles_n);
+        if (im2col) hipLaunchKernelGGL((gemm_kc_split_kernel<128, 128, true, 1, true, bf16_t>), g16, dim3(512), 2 * 256 * 80, st, p);
+        else hipLaunchKernelGGL((gemm_kc_split_kernel<128, 128, false, 1, true, bf16_t>), g16, dim3(512), 2 * 256 * 80, st, p);
+        PA2D_CHECK_LAUNCH();
+        return PA2D_OK;
     }
     if (im2col && conv_halo_applies(p)) return launch_conv_halo(p, st);
     const dim3 grid(ceil_div(tiles_m, 8) * 8 * tiles_n);

@@ -129,3 +129,65 @@ static inline long long ceil_div_ll(long long a, long long b) { return (a + b - 
 struct ReduceSegs { int nseg; long long begin[5]; float* dst[4]; };
 int pa2d_launch_reduce_segs(const float* slab, int nslab, long long count, const ReduceSegs& segs, int accumulate,
                             hipStream_t st);
+
+// ---- activation element types: fp32, or bf16 STORAGE (the *_bf16 entry points: activations, saved tensors and
+// inter-kernel gradients live in HBM as bf16; parameters, statistics, partial sums and accumulators stay fp32).
+// Everything is computed in fp32 registers; these helpers are the only place where the storage type shows.
+typedef __bf16 bf16_t;
+template <typename T> struct Act;
+template <> struct Act<float> {
+    static constexpr unsigned ES = 4;
+    static __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+    static __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+    static __device__ __forceinline__ float ld1(const float* p) { return *p; }
+    // buffer-descriptor forms (byte offset; OOB_OFF lanes read 0 / drop the store)
+    static __device__ __forceinline__ float4 bld4(__amdgpu_buffer_rsrc_t r, unsigned off) { return buf_load4(r, off); }
+    static __device__ __forceinline__ float2 bld2(__amdgpu_buffer_rsrc_t r, unsigned off) { return buf_load2(r, off); }
+    static __device__ __forceinline__ float bld1(__amdgpu_buffer_rsrc_t r, unsigned off) { return buf_load1(r, off); }
+    static __device__ __forceinline__ void bst4(__amdgpu_buffer_rsrc_t r, unsigned off, float4 v) { buf_store4(r, off, v); }
+    static __device__ __forceinline__ void bst1(__amdgpu_buffer_rsrc_t r, unsigned off, float v) { buf_store1(r, off, v); }
+};
+__device__ __forceinline__ float bf16_bits_to_f32(unsigned short b) { return __uint_as_float((unsigned)b << 16); }
+__device__ __forceinline__ unsigned short f32_to_bf16_bits(float x) {        // round to nearest even (hardware cvt)
+    const bf16_t h = (bf16_t)x;
+    return __builtin_bit_cast(unsigned short, h);
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    return (unsigned)f32_to_bf16_bits(lo) | ((unsigned)f32_to_bf16_bits(hi) << 16);
+}
+template <> struct Act<bf16_t> {
+    static constexpr unsigned ES = 2;
+    static __device__ __forceinline__ float4 unpack4(uint2 q) {
+        return make_float4(__uint_as_float(q.x << 16), __uint_as_float(q.x & 0xFFFF0000u), __uint_as_float(q.y << 16),
+                           __uint_as_float(q.y & 0xFFFF0000u));
+    }
+    static __device__ __forceinline__ float4 ld4(const bf16_t* p) { return unpack4(*reinterpret_cast<const uint2*>(p)); }
+    static __device__ __forceinline__ void st4(bf16_t* p, float4 v) {
+        *reinterpret_cast<uint2*>(p) = make_uint2(pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w));
+    }
+    static __device__ __forceinline__ float ld1(const bf16_t* p) { return (float)*p; }
+    static __device__ __forceinline__ float4 bld4(__amdgpu_buffer_rsrc_t r, unsigned off) {
+        typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
+        const u32x2_ q = __builtin_amdgcn_raw_buffer_load_b64(r, off, 0, 0);
+        return unpack4(make_uint2(q.x, q.y));
+    }
+    static __device__ __forceinline__ float2 bld2(__amdgpu_buffer_rsrc_t r, unsigned off) {
+        const unsigned q = __builtin_amdgcn_raw_buffer_load_b32(r, off, 0, 0);
+        return make_float2(__uint_as_float(q << 16), __uint_as_float(q & 0xFFFF0000u));
+    }
+    static __device__ __forceinline__ float bld1(__amdgpu_buffer_rsrc_t r, unsigned off) {
+        return bf16_bits_to_f32(__builtin_amdgcn_raw_buffer_load_b16(r, off, 0, 0));
+    }
+    static __device__ __forceinline__ void bst4(__amdgpu_buffer_rsrc_t r, unsigned off, float4 v) {
+        typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
+        const u32x2_ q = {pack_bf16x2(v.x, v.y), pack_bf16x2(v.z, v.w)};
+        __builtin_amdgcn_raw_buffer_store_b64(q, r, off, 0, 0);
+    }
+    static __device__ __forceinline__ void bst1(__amdgpu_buffer_rsrc_t r, unsigned off, float v) {
+        __builtin_amdgcn_raw_buffer_store_b16(f32_to_bf16_bits(v), r, off, 0, 0);
+    }
+};
+// buffer descriptor over any element type
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_v(const void* base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}

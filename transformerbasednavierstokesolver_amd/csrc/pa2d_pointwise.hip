@@ -9,8 +9,9 @@ int pa2d_launch_reduce(const float* slab, int nslab, long long count, float* out
 
 #define LN_MAXV 4   // float4 per lane -> C <= 1024
 
-__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                            const float* __restrict__ b, float* __restrict__ y,
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ g,
+                                                            const float* __restrict__ b, T* __restrict__ y,
                                                             float* __restrict__ mean, float* __restrict__ rstd,
                                                             int rows, int C, float eps) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -18,13 +19,13 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
     const float4* g4 = reinterpret_cast<const float4*>(g);
     const float4* b4 = reinterpret_cast<const float4*>(b);
     for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
-        const float4* x4 = reinterpret_cast<const float4*>(x + (size_t)row * C);
+        const T* xrow = x + (size_t)row * C;
         float4 v[LN_MAXV];
         float s = 0.f;
 #pragma unroll
         for (int k = 0; k < LN_MAXV; ++k) {
             const int i = lane + 64 * k;
-            v[k] = i < nvec ? x4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            v[k] = i < nvec ? Act<T>::ld4(xrow + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
             s += v[k].x + v[k].y + v[k].z + v[k].w;
         }
         const float mu = wave_sum(s) / C;
@@ -37,14 +38,14 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
             }
         }
         const float rs = 1.0f / sqrtf(wave_sum(q) / C + eps);
-        float4* y4 = reinterpret_cast<float4*>(y + (size_t)row * C);
+        T* yrow = y + (size_t)row * C;
 #pragma unroll
         for (int k = 0; k < LN_MAXV; ++k) {
             const int i = lane + 64 * k;
             if (i < nvec) {
                 const float4 gg = g4[i], bb = b4[i];
-                y4[i] = make_float4((v[k].x - mu) * rs * gg.x + bb.x, (v[k].y - mu) * rs * gg.y + bb.y,
-                                    (v[k].z - mu) * rs * gg.z + bb.z, (v[k].w - mu) * rs * gg.w + bb.w);
+                Act<T>::st4(yrow + 4 * i, make_float4((v[k].x - mu) * rs * gg.x + bb.x, (v[k].y - mu) * rs * gg.y + bb.y,
+                                                      (v[k].z - mu) * rs * gg.z + bb.z, (v[k].w - mu) * rs * gg.w + bb.w));
             }
         }
         if (lane == 0) {
@@ -55,11 +56,12 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const float* __restr
 }
 
 // dx = rstd * (g*dy - mean_c(g*dy) - xhat * mean_c(g*dy*xhat)) (+ dres);  partial[blk] = [dg | db]
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd,
                                                             const float* __restrict__ g,
-                                                            const float* __restrict__ dres, float* __restrict__ dx,
+                                                            const T* __restrict__ dres, T* __restrict__ dx,
                                                             float* __restrict__ partial, int rows, int C,
                                                             int rows_per_block) {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [4 waves][2][C]
@@ -77,8 +79,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(rows, r0 + rows_per_block);
     for (int row = r0 + wave; row < r1; row += 4) {
-        const float4* x4 = reinterpret_cast<const float4*>(x + (size_t)row * C);
-        const float4* d4 = reinterpret_cast<const float4*>(dy + (size_t)row * C);
+        const T* xrow = x + (size_t)row * C;
+        const T* drow = dy + (size_t)row * C;
         const float mu = mean[row], rs = rstd[row];
         float4 xh[LN_MAXV], gd[LN_MAXV];
         float s1 = 0.f, s2 = 0.f;
@@ -86,7 +88,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
         for (int k = 0; k < LN_MAXV; ++k) {
             const int i = lane + 64 * k;
             if (i < nvec) {
-                const float4 xv = x4[i], dv = d4[i];
+                const float4 xv = Act<T>::ld4(xrow + 4 * i), dv = Act<T>::ld4(drow + 4 * i);
                 xh[k] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
                 gd[k] = make_float4(gv[k].x * dv.x, gv[k].y * dv.y, gv[k].z * dv.z, gv[k].w * dv.w);
                 s1 += gd[k].x + gd[k].y + gd[k].z + gd[k].w;
@@ -99,19 +101,19 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             }
         }
         const float c1 = wave_sum(s1) / C, c2 = wave_sum(s2) / C;
-        float4* o4 = reinterpret_cast<float4*>(dx + (size_t)row * C);
-        const float4* r4 = dres ? reinterpret_cast<const float4*>(dres + (size_t)row * C) : nullptr;
+        T* orow = dx + (size_t)row * C;
+        const T* rrow = dres ? dres + (size_t)row * C : nullptr;
 #pragma unroll
         for (int k = 0; k < LN_MAXV; ++k) {
             const int i = lane + 64 * k;
             if (i < nvec) {
                 float4 o = make_float4(rs * (gd[k].x - c1 - xh[k].x * c2), rs * (gd[k].y - c1 - xh[k].y * c2),
                                        rs * (gd[k].z - c1 - xh[k].z * c2), rs * (gd[k].w - c1 - xh[k].w * c2));
-                if (r4) {
-                    const float4 rr = r4[i];
+                if (rrow) {
+                    const float4 rr = Act<T>::ld4(rrow + 4 * i);
                     o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
                 }
-                o4[i] = o;
+                Act<T>::st4(orow + 4 * i, o);
             }
         }
     }
@@ -131,19 +133,19 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 
 // ---------------------------------------------------------------------------------------------
 // narrow head: y[n][o] = xn[n] . W[o] + b[o],  O <= 8
-template <int O>
-__global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__ xn, const float* __restrict__ w,
+template <int O, typename T>
+__global__ __launch_bounds__(256) void head_fwd_kernel(const T* __restrict__ xn, const float* __restrict__ w,
                                                        const float* __restrict__ b, float* __restrict__ y, int rows,
                                                        int C, int out_dim) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nvec = C >> 2;
     for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
-        const float4* x4 = reinterpret_cast<const float4*>(xn + (size_t)row * C);
+        const T* xrow = xn + (size_t)row * C;
         float acc[O];
 #pragma unroll
         for (int o = 0; o < O; ++o) acc[o] = 0.f;
         for (int i = lane; i < nvec; i += 64) {
-            const float4 xv = x4[i];
+            const float4 xv = Act<T>::ld4(xrow + 4 * i);
 #pragma unroll
             for (int o = 0; o < O; ++o)
                 if (o < out_dim) {
@@ -160,9 +162,9 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(const float* __restrict__
 }
 
 // dxn[n][c] = sum_o dy[n][o] W[o][c];  partial[blk] = [dW (out_dim*C) | db (out_dim)]
-template <int O>
-__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ xn,
-                                                       const float* __restrict__ w, float* __restrict__ dxn,
+template <int O, typename T>
+__global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__ dy, const T* __restrict__ xn,
+                                                       const float* __restrict__ w, T* __restrict__ dxn,
                                                        float* __restrict__ partial, int rows, int C, int out_dim,
                                                        int rows_per_block) {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [4 waves][out_dim*C + out_dim]
@@ -183,10 +185,10 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
             g[o] = o < out_dim ? dy[(size_t)row * out_dim + o] : 0.f;
             dbacc[o] += g[o];
         }
-        const float4* x4 = reinterpret_cast<const float4*>(xn + (size_t)row * C);
-        float4* o4 = reinterpret_cast<float4*>(dxn + (size_t)row * C);
+        const T* xrow = xn + (size_t)row * C;
+        T* orow = dxn + (size_t)row * C;
         for (int i = lane; i < nvec; i += 64) {
-            const float4 xv = x4[i];
+            const float4 xv = Act<T>::ld4(xrow + 4 * i);
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int o = 0; o < O; ++o)
@@ -198,7 +200,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(const float* __restrict__
                     mv.x += g[o] * xv.x; mv.y += g[o] * xv.y; mv.z += g[o] * xv.z; mv.w += g[o] * xv.w;
                     *m4 = mv;
                 }
-            o4[i] = acc;
+            Act<T>::st4(orow + 4 * i, acc);
         }
     }
     if (lane == 0)
@@ -221,36 +223,32 @@ static int row_blocks(int rows) {
     return b < 1 ? 1 : b;
 }
 
-extern "C" {
-
-int pa2d_layernorm_fwd(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd, int rows,
-                       int C, float eps, hipStream_t st) {
+template <typename T>
+static int ln_fwd_t(const T* x, const float* g, const float* b, T* y, float* mean, float* rstd, int rows, int C, float eps,
+                    hipStream_t st) {
     if ((C & 3) || C > 256 * LN_MAXV) return PA2D_ERR_UNSUPPORTED;
     if (rows <= 0) return PA2D_OK;
     int grid = ceil_div(rows, 4);
     if (grid > 8192) grid = 8192;
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(grid), dim3(256), 0, st, x, g, b, y, mean, rstd, rows, C, eps);
+    hipLaunchKernelGGL((layernorm_fwd_kernel<T>), dim3(grid), dim3(256), 0, st, x, g, b, y, mean, rstd, rows, C, eps);
     PA2D_CHECK_LAUNCH();
     return PA2D_OK;
 }
 
-size_t pa2d_layernorm_bwd_workspace(int rows, int C) { return sizeof(float) * ((size_t)row_blocks(rows) + 1) * 2 * C; }
-
-// dres (optional): gradient flowing through the residual branch, added to dx (dx may alias dres)
-int pa2d_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* g,
-                       const float* dres, float* dx, float* dg, float* db, void* ws, size_t ws_bytes, int rows, int C,
-                       int accumulate, hipStream_t st) {
+template <typename T>
+static int ln_bwd_t(const T* dy, const T* x, const float* mean, const float* rstd, const float* g, const T* dres, T* dx,
+                    float* dg, float* db, void* ws, size_t ws_bytes, int rows, int C, int accumulate, hipStream_t st) {
     if ((C & 3) || C > 256 * LN_MAXV) return PA2D_ERR_UNSUPPORTED;
     if (rows <= 0) {
         if (accumulate) return PA2D_OK;
         const int rz = pa2d_zero(dg, sizeof(float) * C, st);
         return rz ? rz : pa2d_zero(db, sizeof(float) * C, st);
     }
-    if (ws_bytes < pa2d_layernorm_bwd_workspace(rows, C)) return PA2D_ERR_WORKSPACE;
+    if (ws_bytes < sizeof(float) * ((size_t)row_blocks(rows) + 1) * 2 * C) return PA2D_ERR_WORKSPACE;
     const int nb = row_blocks(rows);
     const int rpb = ceil_div(rows, nb);
     float* part = (float*)ws;
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(nb), dim3(256), sizeof(float) * 8 * C, st, dy, x, mean, rstd, g,
+    hipLaunchKernelGGL((layernorm_bwd_kernel<T>), dim3(nb), dim3(256), sizeof(float) * 8 * C, st, dy, x, mean, rstd, g,
                        dres, dx, part, rows, C, rpb);
     PA2D_CHECK_LAUNCH();
     ReduceSegs segs;
@@ -260,18 +258,81 @@ int pa2d_layernorm_bwd(const float* dy, const float* x, const float* mean, const
     return pa2d_launch_reduce_segs(part, nb, 2 * C, segs, accumulate, st);
 }
 
-int pa2d_head_fwd(const float* xn, const float* w, const float* b, float* y, int rows, int C, int out_dim,
-                  hipStream_t st) {
+template <typename T>
+static int head_fwd_t(const T* xn, const float* w, const float* b, float* y, int rows, int C, int out_dim, hipStream_t st) {
     if ((C & 3) || out_dim < 1 || out_dim > 8) return PA2D_ERR_UNSUPPORTED;
     if (rows <= 0) return PA2D_OK;
     int grid = ceil_div(rows, 4);
     if (grid > 8192) grid = 8192;
-    if (out_dim == 1) hipLaunchKernelGGL((head_fwd_kernel<1>), dim3(grid), dim3(256), 0, st, xn, w, b, y, rows, C, out_dim);
-    else if (out_dim == 2) hipLaunchKernelGGL((head_fwd_kernel<2>), dim3(grid), dim3(256), 0, st, xn, w, b, y, rows, C, out_dim);
-    else if (out_dim <= 4) hipLaunchKernelGGL((head_fwd_kernel<4>), dim3(grid), dim3(256), 0, st, xn, w, b, y, rows, C, out_dim);
-    else hipLaunchKernelGGL((head_fwd_kernel<8>), dim3(grid), dim3(256), 0, st, xn, w, b, y, rows, C, out_dim);
+    if (out_dim == 1) hipLaunchKernelGGL((head_fwd_kernel<1, T>), dim3(grid), dim3(256), 0, st, xn, w, b, y, rows, C, out_dim);
+    else if (out_dim == 2) hipLaunchKernelGGL((head_fwd_kernel<2, T>), dim3(grid), dim3(256), 0, st, xn, w, b, y, rows, C, out_dim);
+    else if (out_dim <= 4) hipLaunchKernelGGL((head_fwd_kernel<4, T>), dim3(grid), dim3(256), 0, st, xn, w, b, y, rows, C, out_dim);
+    else hipLaunchKernelGGL((head_fwd_kernel<8, T>), dim3(grid), dim3(256), 0, st, xn, w, b, y, rows, C, out_dim);
     PA2D_CHECK_LAUNCH();
     return PA2D_OK;
+}
+
+template <typename T>
+static int head_bwd_t(const float* dy, const T* xn, const float* w, T* dxn, float* dw, float* db, void* ws, size_t ws_bytes,
+                      int rows, int C, int out_dim, int accumulate, hipStream_t st) {
+    if ((C & 3) || out_dim < 1 || out_dim > 8) return PA2D_ERR_UNSUPPORTED;
+    if (rows <= 0) {
+        if (accumulate) return PA2D_OK;
+        const int rz = pa2d_zero(dw, sizeof(float) * out_dim * C, st);
+        return rz ? rz : pa2d_zero(db, sizeof(float) * out_dim, st);
+    }
+    const int rec = out_dim * C + out_dim;
+    if (ws_bytes < sizeof(float) * ((size_t)row_blocks(rows) + 1) * rec) return PA2D_ERR_WORKSPACE;
+    const size_t smem = sizeof(float) * 4 * rec;
+    if (smem > 64 * 1024) return PA2D_ERR_UNSUPPORTED;
+    const int nb = row_blocks(rows);
+    const int rpb = ceil_div(rows, nb);
+    float* part = (float*)ws;
+    if (out_dim == 1) hipLaunchKernelGGL((head_bwd_kernel<1, T>), dim3(nb), dim3(256), smem, st, dy, xn, w, dxn, part, rows, C, out_dim, rpb);
+    else if (out_dim == 2) hipLaunchKernelGGL((head_bwd_kernel<2, T>), dim3(nb), dim3(256), smem, st, dy, xn, w, dxn, part, rows, C, out_dim, rpb);
+    else if (out_dim <= 4) hipLaunchKernelGGL((head_bwd_kernel<4, T>), dim3(nb), dim3(256), smem, st, dy, xn, w, dxn, part, rows, C, out_dim, rpb);
+    else hipLaunchKernelGGL((head_bwd_kernel<8, T>), dim3(nb), dim3(256), smem, st, dy, xn, w, dxn, part, rows, C, out_dim, rpb);
+    PA2D_CHECK_LAUNCH();
+    ReduceSegs segs;
+    segs.nseg = 2;
+    segs.begin[0] = 0; segs.begin[1] = (long long)out_dim * C; segs.begin[2] = rec; segs.begin[3] = segs.begin[4] = rec;
+    segs.dst[0] = dw; segs.dst[1] = db; segs.dst[2] = segs.dst[3] = nullptr;
+    return pa2d_launch_reduce_segs(part, nb, rec, segs, accumulate, st);
+}
+
+extern "C" {
+
+int pa2d_layernorm_fwd(const float* x, const float* g, const float* b, float* y, float* mean, float* rstd, int rows,
+                       int C, float eps, hipStream_t st) {
+    return ln_fwd_t<float>(x, g, b, y, mean, rstd, rows, C, eps, st);
+}
+int pa2d_layernorm_fwd_bf16(const void* x, const float* g, const float* b, void* y, float* mean, float* rstd, int rows,
+                            int C, float eps, hipStream_t st) {
+    return ln_fwd_t<bf16_t>((const bf16_t*)x, g, b, (bf16_t*)y, mean, rstd, rows, C, eps, st);
+}
+
+size_t pa2d_layernorm_bwd_workspace(int rows, int C) { return sizeof(float) * ((size_t)row_blocks(rows) + 1) * 2 * C; }
+
+// dres (optional): gradient flowing through the residual branch, added to dx (dx may alias dres)
+int pa2d_layernorm_bwd(const float* dy, const float* x, const float* mean, const float* rstd, const float* g,
+                       const float* dres, float* dx, float* dg, float* db, void* ws, size_t ws_bytes, int rows, int C,
+                       int accumulate, hipStream_t st) {
+    return ln_bwd_t<float>(dy, x, mean, rstd, g, dres, dx, dg, db, ws, ws_bytes, rows, C, accumulate, st);
+}
+int pa2d_layernorm_bwd_bf16(const void* dy, const void* x, const float* mean, const float* rstd, const float* g,
+                            const void* dres, void* dx, float* dg, float* db, void* ws, size_t ws_bytes, int rows, int C,
+                            int accumulate, hipStream_t st) {
+    return ln_bwd_t<bf16_t>((const bf16_t*)dy, (const bf16_t*)x, mean, rstd, g, (const bf16_t*)dres, (bf16_t*)dx, dg, db, ws,
+                            ws_bytes, rows, C, accumulate, st);
+}
+
+int pa2d_head_fwd(const float* xn, const float* w, const float* b, float* y, int rows, int C, int out_dim,
+                  hipStream_t st) {
+    return head_fwd_t<float>(xn, w, b, y, rows, C, out_dim, st);
+}
+int pa2d_head_fwd_bf16(const void* xn, const float* w, const float* b, float* y, int rows, int C, int out_dim,
+                       hipStream_t st) {
+    return head_fwd_t<bf16_t>((const bf16_t*)xn, w, b, y, rows, C, out_dim, st);
 }
 
 size_t pa2d_head_bwd_workspace(int rows, int C, int out_dim) {
@@ -280,29 +341,11 @@ size_t pa2d_head_bwd_workspace(int rows, int C, int out_dim) {
 
 int pa2d_head_bwd(const float* dy, const float* xn, const float* w, float* dxn, float* dw, float* db, void* ws,
                   size_t ws_bytes, int rows, int C, int out_dim, int accumulate, hipStream_t st) {
-    if ((C & 3) || out_dim < 1 || out_dim > 8) return PA2D_ERR_UNSUPPORTED;
-    if (rows <= 0) {
-        if (accumulate) return PA2D_OK;
-        const int rz = pa2d_zero(dw, sizeof(float) * out_dim * C, st);
-        return rz ? rz : pa2d_zero(db, sizeof(float) * out_dim, st);
-    }
-    if (ws_bytes < pa2d_head_bwd_workspace(rows, C, out_dim)) return PA2D_ERR_WORKSPACE;
-    const int rec = out_dim * C + out_dim;
-    const size_t smem = sizeof(float) * 4 * rec;
-    if (smem > 64 * 1024) return PA2D_ERR_UNSUPPORTED;
-    const int nb = row_blocks(rows);
-    const int rpb = ceil_div(rows, nb);
-    float* part = (float*)ws;
-    if (out_dim == 1) hipLaunchKernelGGL((head_bwd_kernel<1>), dim3(nb), dim3(256), smem, st, dy, xn, w, dxn, part, rows, C, out_dim, rpb);
-    else if (out_dim == 2) hipLaunchKernelGGL((head_bwd_kernel<2>), dim3(nb), dim3(256), smem, st, dy, xn, w, dxn, part, rows, C, out_dim, rpb);
-    else if (out_dim <= 4) hipLaunchKernelGGL((head_bwd_kernel<4>), dim3(nb), dim3(256), smem, st, dy, xn, w, dxn, part, rows, C, out_dim, rpb);
-    else hipLaunchKernelGGL((head_bwd_kernel<8>), dim3(nb), dim3(256), smem, st, dy, xn, w, dxn, part, rows, C, out_dim, rpb);
-    PA2D_CHECK_LAUNCH();
-    ReduceSegs segs;
-    segs.nseg = 2;
-    segs.begin[0] = 0; segs.begin[1] = (long long)out_dim * C; segs.begin[2] = rec; segs.begin[3] = segs.begin[4] = rec;
-    segs.dst[0] = dw; segs.dst[1] = db; segs.dst[2] = segs.dst[3] = nullptr;
-    return pa2d_launch_reduce_segs(part, nb, rec, segs, accumulate, st);
+    return head_bwd_t<float>(dy, xn, w, dxn, dw, db, ws, ws_bytes, rows, C, out_dim, accumulate, st);
+}
+int pa2d_head_bwd_bf16(const float* dy, const void* xn, const float* w, void* dxn, float* dw, float* db, void* ws,
+                       size_t ws_bytes, int rows, int C, int out_dim, int accumulate, hipStream_t st) {
+    return head_bwd_t<bf16_t>(dy, (const bf16_t*)xn, w, (bf16_t*)dxn, dw, db, ws, ws_bytes, rows, C, out_dim, accumulate, st);
 }
 
 int pa2d_act_bwd(const float* dy, const float* pre, float* out, long long n, int act, hipStream_t st) {

@@ -86,24 +86,26 @@ __device__ __forceinline__ void load_kfrag(const float* row, bool valid, int kq,
 }
 
 // same fragment through a buffer descriptor: masked lanes (off == OOB_OFF) read 0, no branch
-template <int D>
+// (T = storage type of the activations: float or bf16; offsets are BYTE offsets, ES = sizeof(T))
+template <int D, typename T>
 __device__ __forceinline__ void buf_kfrag(__amdgpu_buffer_rsrc_t r, unsigned off, int kq, float (&f)[SCfg<D>::KS]) {
     constexpr int VEC = SCfg<D>::VEC, NV = SCfg<D>::NV;
+    constexpr unsigned ES = Act<T>::ES;
 #pragma unroll
     for (int v = 0; v < NV; ++v) {
         if constexpr (VEC == 4) {
-            const float4 q = buf_load4(r, off == OOB_OFF ? OOB_OFF : off + (16 * v + 4 * kq) * 4u);
+            const float4 q = Act<T>::bld4(r, off == OOB_OFF ? OOB_OFF : off + (16 * v + 4 * kq) * ES);
             f[4 * v + 0] = q.x; f[4 * v + 1] = q.y; f[4 * v + 2] = q.z; f[4 * v + 3] = q.w;
         } else {
-            const float2 q = buf_load2(r, off == OOB_OFF ? OOB_OFF : off + (8 * v + 2 * kq) * 4u);
+            const float2 q = Act<T>::bld2(r, off == OOB_OFF ? OOB_OFF : off + (8 * v + 2 * kq) * ES);
             f[2 * v + 0] = q.x; f[2 * v + 1] = q.y;
         }
     }
 }
 
 struct SliceParams {
-    const float* xm; long long ldx;     // x_mid rows: xm[(b*N+n)*ldx + h*D + d]
-    const float* v; long long ldv;      // values scattered (fx_mid forward, dY in backward phase A)
+    const void* xm; long long ldx;      // x_mid rows: xm[(b*N+n)*ldx + h*D + d]   (float or bf16 storage)
+    const void* v; long long ldv;       // values scattered (fx_mid forward, dY in backward phase A)
     const float* ws; const float* bs; const float* temperature;   // [M,D], [M], [heads]
     float* spart; float* npart;         // [B,heads,nchunk,M,D], [B,heads,nchunk,M] (npart may be null)
     int B, N, heads, M, nchunk, ppc;    // ppc = points per chunk (multiple of 16)
@@ -112,9 +114,10 @@ struct SliceParams {
 };
 
 // S_partial[m][d] = sum_{n in chunk} W[n][m] * V[n][d];  n_partial[m] = sum_n W[n][m]
-template <int D, int MT>
+template <int D, int MT, typename T>
 __global__ __launch_bounds__(256) void slice_scatter_kernel(const SliceParams p) {
     constexpr int KS = SCfg<D>::KS, DT = SCfg<D>::DT;
+    constexpr unsigned ES = Act<T>::ES;
     constexpr int MP = 16 * MT, DP = 16 * DT;
     __shared__ float sbuf[MP * DP];
     __shared__ float nbuf[MP];
@@ -142,20 +145,20 @@ __global__ __launch_bounds__(256) void slice_scatter_kernel(const SliceParams p)
     const int p_begin = chunk * p.ppc;
     const int p_end = min(p.N, p_begin + p.ppc);
     const unsigned row0 = (unsigned)b * (unsigned)p.N;
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.xm, p.x_bytes);
-    const __amdgpu_buffer_rsrc_t rv = make_rsrc(p.v, p.v_bytes);
-    const unsigned ldx4 = (unsigned)p.ldx * 4u, ldv4 = (unsigned)p.ldv * 4u, hcol = (unsigned)(hh * D) * 4u;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc_v(p.xm, p.x_bytes);
+    const __amdgpu_buffer_rsrc_t rv = make_rsrc_v(p.v, p.v_bytes);
+    const unsigned ldx4 = (unsigned)p.ldx * ES, ldv4 = (unsigned)p.ldv * ES, hcol = (unsigned)(hh * D) * ES;
     // group loads: X as k-fragments (lane = point li), V as rows (lane = channel li) — branch-free
     // buffer loads, issued one group ahead so that they fly under the 64 MFMAs of the current group
 #define SC_LOAD(g_, XF, FV)                                                                            \
     {                                                                                                  \
         const int pt_ = (g_) + li;                                                                     \
-        buf_kfrag<D>(rx, pt_ < p_end ? (row0 + pt_) * ldx4 + hcol : OOB_OFF, kq, XF);                   \
+        buf_kfrag<D, T>(rx, pt_ < p_end ? (row0 + pt_) * ldx4 + hcol : OOB_OFF, kq, XF);                \
         _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                \
             const int pr_ = (g_) + 4 * kq + r;                                                         \
             _Pragma("unroll") for (int dt = 0; dt < DT; ++dt) {                                        \
                 const int d_ = 16 * dt + li;                                                           \
-                FV[r][dt] = buf_load1(rv, (pr_ < p_end && d_ < D) ? (row0 + pr_) * ldv4 + hcol + d_ * 4u : OOB_OFF); \
+                FV[r][dt] = Act<T>::bld1(rv, (pr_ < p_end && d_ < D) ? (row0 + pr_) * ldv4 + hcol + d_ * ES : OOB_OFF); \
             }                                                                                          \
         }                                                                                              \
     }
@@ -237,19 +240,20 @@ __global__ __launch_bounds__(256) void slice_scatter_kernel(const SliceParams p)
 }
 
 struct DesliceParams {
-    const float* xm; long long ldx;
+    const void* xm; long long ldx;
     const float* o;                     // [B,heads,M,D]
     const float* ws; const float* bs; const float* temperature;
-    float* y; long long ldy;            // y[(b*N+n)*ldy + h*D + d]
+    void* y; long long ldy;             // y[(b*N+n)*ldy + h*D + d]
     int B, N, heads, M, nchunk, ppc;
     unsigned x_bytes, y_bytes;
     int clamp;
 };
 
 // Y[n][h*D+d] = sum_m W[n][m] * O[m][d]
-template <int D, int MT>
+template <int D, int MT, typename T>
 __global__ __launch_bounds__(256) void deslice_kernel(const DesliceParams p) {
     constexpr int KS = SCfg<D>::KS, DT = SCfg<D>::DT;
+    constexpr unsigned ES = Act<T>::ES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
     const int chunk = blockIdx.x % p.nchunk;
     const int hh = (blockIdx.x / p.nchunk) % p.heads;
@@ -276,16 +280,16 @@ __global__ __launch_bounds__(256) void deslice_kernel(const DesliceParams p) {
     const int p_begin = chunk * p.ppc;
     const int p_end = min(p.N, p_begin + p.ppc);
     const unsigned row0 = (unsigned)b * (unsigned)p.N;
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.xm, p.x_bytes);
-    const __amdgpu_buffer_rsrc_t ry = make_rsrc(p.y, p.y_bytes);
-    const unsigned ldx4 = (unsigned)p.ldx * 4u, ldy4 = (unsigned)p.ldy * 4u, hcol = (unsigned)(hh * D) * 4u;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc_v(p.xm, p.x_bytes);
+    const __amdgpu_buffer_rsrc_t ry = make_rsrc_v(p.y, p.y_bytes);
+    const unsigned ldx4 = (unsigned)p.ldx * ES, ldy4 = (unsigned)p.ldy * ES, hcol = (unsigned)(hh * D) * ES;
     float xf[KS], xf_n[KS];
     int g = p_begin + wave * 16;
-    if (g < p_end) buf_kfrag<D>(rx, g + li < p_end ? (row0 + g + li) * ldx4 + hcol : OOB_OFF, kq, xf);
+    if (g < p_end) buf_kfrag<D, T>(rx, g + li < p_end ? (row0 + g + li) * ldx4 + hcol : OOB_OFF, kq, xf);
     for (; g < p_end; g += 64) {
         const int pt = g + li;
         const bool pv = pt < p_end;
-        if (g + 64 < p_end) buf_kfrag<D>(rx, pt + 64 < p_end ? (row0 + pt + 64) * ldx4 + hcol : OOB_OFF, kq, xf_n);
+        if (g + 64 < p_end) buf_kfrag<D, T>(rx, pt + 64 < p_end ? (row0 + pt + 64) * ldx4 + hcol : OOB_OFF, kq, xf_n);
         f32x4 w[MT];
         float mx = NEG_BIG;
 #pragma unroll
@@ -327,8 +331,8 @@ __global__ __launch_bounds__(256) void deslice_kernel(const DesliceParams p) {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             const int d = 16 * dt + 4 * kq;
-            buf_store4(ry, (pv && d < D) ? (row0 + pt) * ldy4 + hcol + d * 4u : OOB_OFF,
-                       make_float4(yacc[dt][0], yacc[dt][1], yacc[dt][2], yacc[dt][3]));
+            Act<T>::bst4(ry, (pv && d < D) ? (row0 + pt) * ldy4 + hcol + d * ES : OOB_OFF,
+                         make_float4(yacc[dt][0], yacc[dt][1], yacc[dt][2], yacc[dt][3]));
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) xf[ks] = xf_n[ks];
@@ -336,13 +340,13 @@ __global__ __launch_bounds__(256) void deslice_kernel(const DesliceParams p) {
 }
 
 struct SliceBwdParams {
-    const float* xm; long long ldx;     // x_mid
-    const float* fm; long long ldf;     // fx_mid
-    const float* dy; long long lddy;    // gradient w.r.t. de-sliced y
+    const void* xm; long long ldx;      // x_mid
+    const void* fm; long long ldf;      // fx_mid
+    const void* dy; long long lddy;     // gradient w.r.t. de-sliced y
     const float* ws; const float* bs; const float* temperature;
     const float* o; const float* ds; const float* dn;   // [B,heads,M,D] x2, [B,heads,M]
-    float* dxm; long long lddx;         // outputs
-    float* dfm; long long lddf;
+    void* dxm; long long lddx;          // outputs
+    void* dfm; long long lddf;
     float* part;                        // per block: [M*D (dWs) | M (dbs) | 1 (dtau)]
     int B, N, heads, M, nchunk, ppc;
     unsigned x_bytes, f_bytes, dy_bytes, dx_bytes, df_bytes;
@@ -352,9 +356,10 @@ struct SliceBwdParams {
 // Backward phase C (per point): recompute W, then
 //   dW = dY.O^T + F.dS^T + dn ; dL = W*(dW - rowsum(dW*W)) ; dF = W.dS ; dX = dL.Ws/tau
 //   dWs += (dL/tau)^T.X ; dbs += sum dL/tau ; dtau -= sum(dL*L)/tau
-template <int D, int MT>
+template <int D, int MT, typename T>
 __global__ __launch_bounds__(256) void slice_bwd_kernel(const SliceBwdParams p) {
     constexpr int KS = SCfg<D>::KS, DT = SCfg<D>::DT, VEC = SCfg<D>::VEC, NV = SCfg<D>::NV;
+    constexpr unsigned ES = Act<T>::ES;
     constexpr int MP = 16 * MT, DP = 16 * DT, P = DP + 4;   // LDS row pitch (floats), 16-B aligned
     constexpr int TP = MP + 4;                              // pitch of the per-wave dL transpose tile
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -405,26 +410,26 @@ __global__ __launch_bounds__(256) void slice_bwd_kernel(const SliceBwdParams p) 
     const int p_begin = chunk * p.ppc;
     const int p_end = min(p.N, p_begin + p.ppc);
     const unsigned row0 = (unsigned)b * (unsigned)p.N;
-    const __amdgpu_buffer_rsrc_t rx = make_rsrc(p.xm, p.x_bytes);
-    const __amdgpu_buffer_rsrc_t rf = make_rsrc(p.fm, p.f_bytes);
-    const __amdgpu_buffer_rsrc_t rg = make_rsrc(p.dy, p.dy_bytes);
-    const __amdgpu_buffer_rsrc_t rdx = make_rsrc(p.dxm, p.dx_bytes);
-    const __amdgpu_buffer_rsrc_t rdf = make_rsrc(p.dfm, p.df_bytes);
-    const unsigned ldx4 = (unsigned)p.ldx * 4u, ldf4 = (unsigned)p.ldf * 4u, ldg4 = (unsigned)p.lddy * 4u;
-    const unsigned lddx4 = (unsigned)p.lddx * 4u, lddf4 = (unsigned)p.lddf * 4u, hcol = (unsigned)(hh * D) * 4u;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc_v(p.xm, p.x_bytes);
+    const __amdgpu_buffer_rsrc_t rf = make_rsrc_v(p.fm, p.f_bytes);
+    const __amdgpu_buffer_rsrc_t rg = make_rsrc_v(p.dy, p.dy_bytes);
+    const __amdgpu_buffer_rsrc_t rdx = make_rsrc_v(p.dxm, p.dx_bytes);
+    const __amdgpu_buffer_rsrc_t rdf = make_rsrc_v(p.dfm, p.df_bytes);
+    const unsigned ldx4 = (unsigned)p.ldx * ES, ldf4 = (unsigned)p.ldf * ES, ldg4 = (unsigned)p.lddy * ES;
+    const unsigned lddx4 = (unsigned)p.lddx * ES, lddf4 = (unsigned)p.lddf * ES, hcol = (unsigned)(hh * D) * ES;
     // one-group-ahead prefetch of the three k-fragments and of the X rows used by dWs
 #define BW_LOAD(g_, XF, FF, GF, XV)                                                                    \
     {                                                                                                  \
         const int pt_ = (g_) + li;                                                                     \
         const bool ok_ = pt_ < p_end;                                                                  \
-        buf_kfrag<D>(rx, ok_ ? (row0 + pt_) * ldx4 + hcol : OOB_OFF, kq, XF);                           \
-        buf_kfrag<D>(rf, ok_ ? (row0 + pt_) * ldf4 + hcol : OOB_OFF, kq, FF);                           \
-        buf_kfrag<D>(rg, ok_ ? (row0 + pt_) * ldg4 + hcol : OOB_OFF, kq, GF);                           \
+        buf_kfrag<D, T>(rx, ok_ ? (row0 + pt_) * ldx4 + hcol : OOB_OFF, kq, XF);                        \
+        buf_kfrag<D, T>(rf, ok_ ? (row0 + pt_) * ldf4 + hcol : OOB_OFF, kq, FF);                        \
+        buf_kfrag<D, T>(rg, ok_ ? (row0 + pt_) * ldg4 + hcol : OOB_OFF, kq, GF);                        \
         _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                                \
             const int pr_ = (g_) + 4 * kq + r;                                                         \
             _Pragma("unroll") for (int dt = 0; dt < DT; ++dt) {                                        \
                 const int d_ = 16 * dt + li;                                                           \
-                XV[r][dt] = buf_load1(rx, (pr_ < p_end && d_ < D) ? (row0 + pr_) * ldx4 + hcol + d_ * 4u : OOB_OFF); \
+                XV[r][dt] = Act<T>::bld1(rx, (pr_ < p_end && d_ < D) ? (row0 + pr_) * ldx4 + hcol + d_ * ES : OOB_OFF); \
             }                                                                                          \
         }                                                                                              \
     }
@@ -537,11 +542,11 @@ __global__ __launch_bounds__(256) void slice_bwd_kernel(const SliceBwdParams p) 
         for (int dt = 0; dt < DT; ++dt) {
             const int d = 16 * dt + 4 * kq;
             const bool ok = pv && d < D;
-            buf_store4(rdf, ok ? (row0 + pt) * lddf4 + hcol + d * 4u : OOB_OFF,
-                       make_float4(facc[dt][0], facc[dt][1], facc[dt][2], facc[dt][3]));
-            buf_store4(rdx, ok ? (row0 + pt) * lddx4 + hcol + d * 4u : OOB_OFF,
-                       make_float4(xacc[dt][0] * inv_tau, xacc[dt][1] * inv_tau, xacc[dt][2] * inv_tau,
-                                   xacc[dt][3] * inv_tau));
+            Act<T>::bst4(rdf, ok ? (row0 + pt) * lddf4 + hcol + d * ES : OOB_OFF,
+                         make_float4(facc[dt][0], facc[dt][1], facc[dt][2], facc[dt][3]));
+            Act<T>::bst4(rdx, ok ? (row0 + pt) * lddx4 + hcol + d * ES : OOB_OFF,
+                         make_float4(xacc[dt][0] * inv_tau, xacc[dt][1] * inv_tau, xacc[dt][2] * inv_tau,
+                                     xacc[dt][3] * inv_tau));
         }
         // dWs += dL^T . X : transpose the 16 x M tile of dL through wave-private LDS so that the
         // slice index lands on the lane (A operand i = m, k = point)
@@ -622,12 +627,14 @@ __global__ void dtau_finalize_kernel(const float* __restrict__ part, const float
 // ---------------------------------------------------------------------------------------------
 // dispatch over the compile-time (D, MT) grid
 template <int D, int MT>
-static void launch_scatter_t(const SliceParams& p, int grid, hipStream_t st) {
-    hipLaunchKernelGGL((slice_scatter_kernel<D, MT>), dim3(grid), dim3(256), 0, st, p);
+static void launch_scatter_t(const SliceParams& p, int grid, hipStream_t st, bool bf) {
+    if (bf) hipLaunchKernelGGL((slice_scatter_kernel<D, MT, bf16_t>), dim3(grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((slice_scatter_kernel<D, MT, float>), dim3(grid), dim3(256), 0, st, p);
 }
 template <int D, int MT>
-static void launch_deslice_t(const DesliceParams& p, int grid, hipStream_t st) {
-    hipLaunchKernelGGL((deslice_kernel<D, MT>), dim3(grid), dim3(256), 0, st, p);
+static void launch_deslice_t(const DesliceParams& p, int grid, hipStream_t st, bool bf) {
+    if (bf) hipLaunchKernelGGL((deslice_kernel<D, MT, bf16_t>), dim3(grid), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((deslice_kernel<D, MT, float>), dim3(grid), dim3(256), 0, st, p);
 }
 template <int D, int MT>
 static size_t bwd_smem_bytes() {
@@ -636,14 +643,17 @@ static size_t bwd_smem_bytes() {
     return sizeof(float) * (size_t)(3 * MP * P + 2 * MP + 4 * 16 * TP);
 }
 template <int D, int MT>
-static int launch_bwd_t(const SliceBwdParams& p, int grid, hipStream_t st) {
+static int launch_bwd_t(const SliceBwdParams& p, int grid, hipStream_t st, bool bf) {
     const size_t smem = bwd_smem_bytes<D, MT>();
     if (smem > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&slice_bwd_kernel<D, MT>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        hipError_t e = bf ? hipFuncSetAttribute(reinterpret_cast<const void*>(&slice_bwd_kernel<D, MT, bf16_t>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)
+                          : hipFuncSetAttribute(reinterpret_cast<const void*>(&slice_bwd_kernel<D, MT, float>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
     }
-    hipLaunchKernelGGL((slice_bwd_kernel<D, MT>), dim3(grid), dim3(256), smem, st, p);
+    if (bf) hipLaunchKernelGGL((slice_bwd_kernel<D, MT, bf16_t>), dim3(grid), dim3(256), smem, st, p);
+    else hipLaunchKernelGGL((slice_bwd_kernel<D, MT, float>), dim3(grid), dim3(256), smem, st, p);
     return PA2D_OK;
 }
 
@@ -689,15 +699,17 @@ int pa2d_slice_nchunk(int B, int N, int heads) {
     return ceil_div(N, ppc);
 }
 static int ppc_for(int N, int nchunk) { return ceil_div(ceil_div(N, nchunk), 16) * 16; }
+size_t pa2d_slice_bwd_workspace(int B, int N, int heads, int D, int M);
 
-// spart [B,heads,nchunk,M,D], npart [B,heads,nchunk,M] (NULL to skip the norm)
-int pa2d_slice_scatter(const float* xm, long long ldx, const float* v, long long ldv, const float* ws,
-                       const float* bs, const float* temperature, float* spart, float* npart, int B, int N,
-                       int heads, int D, int M, int clamp_temperature, hipStream_t st, hipEvent_t ev_start,
-                       hipEvent_t ev_stop) {
+// spart [B,heads,nchunk,M,D], npart [B,heads,nchunk,M] (NULL to skip the norm); bf: activations stored as bf16
+static int slice_scatter_impl(const void* xm, long long ldx, const void* v, long long ldv, const float* ws,
+                              const float* bs, const float* temperature, float* spart, float* npart, int B, int N,
+                              int heads, int D, int M, int clamp_temperature, hipStream_t st, hipEvent_t ev_start,
+                              hipEvent_t ev_stop, bool bf) {
     const int mt = mt_for(M);
     if ((ldx & 3) || (D & 7)) return PA2D_ERR_ARG;
     if (B <= 0 || N <= 0) return PA2D_OK;
+    const unsigned long long es = bf ? 2ull : 4ull;
     SliceParams p;
     p.xm = xm; p.ldx = ldx; p.v = v; p.ldv = ldv; p.ws = ws; p.bs = bs; p.temperature = temperature;
     p.spart = spart; p.npart = npart; p.B = B; p.N = N; p.heads = heads; p.M = M; p.clamp = clamp_temperature;
@@ -705,26 +717,27 @@ int pa2d_slice_scatter(const float* xm, long long ldx, const float* v, long long
     p.ppc = ppc_for(N, p.nchunk);
     {
         const unsigned long long rows = (unsigned long long)B * N;
-        const unsigned long long xb = ((rows - 1) * ldx + (unsigned long long)heads * D) * 4ull;
-        const unsigned long long vb = ((rows - 1) * ldv + (unsigned long long)heads * D) * 4ull;
+        const unsigned long long xb = ((rows - 1) * ldx + (unsigned long long)heads * D) * es;
+        const unsigned long long vb = ((rows - 1) * ldv + (unsigned long long)heads * D) * es;
         if (xb >= 0xFFFFFFF0ull || vb >= 0xFFFFFFF0ull) return PA2D_ERR_UNSUPPORTED;
         p.x_bytes = (unsigned)xb; p.v_bytes = (unsigned)vb;
     }
     const int grid = B * heads * p.nchunk;
     if (ev_start && hipEventRecord(ev_start, st) != hipSuccess) return PA2D_ERR_ARG;
-#define CALL_SC(D_, MT_) launch_scatter_t<D_, MT_>(p, grid, st)
+#define CALL_SC(D_, MT_) launch_scatter_t<D_, MT_>(p, grid, st, bf)
     DISPATCH_D(CALL_SC)
     PA2D_CHECK_LAUNCH();
     if (ev_stop && hipEventRecord(ev_stop, st) != hipSuccess) return PA2D_ERR_ARG;
     return PA2D_OK;
 }
 
-int pa2d_deslice_fwd(const float* xm, long long ldx, const float* o, const float* ws, const float* bs,
-                     const float* temperature, float* y, long long ldy, int B, int N, int heads, int D, int M,
-                     int clamp_temperature, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
+static int deslice_impl(const void* xm, long long ldx, const float* o, const float* ws, const float* bs,
+                        const float* temperature, void* y, long long ldy, int B, int N, int heads, int D, int M,
+                        int clamp_temperature, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop, bool bf) {
     const int mt = mt_for(M);
     if ((ldx & 3) || (ldy & 3) || (D & 7)) return PA2D_ERR_ARG;
     if (B <= 0 || N <= 0) return PA2D_OK;
+    const unsigned long long es = bf ? 2ull : 4ull;
     DesliceParams p;
     p.xm = xm; p.ldx = ldx; p.o = o; p.ws = ws; p.bs = bs; p.temperature = temperature; p.y = y; p.ldy = ldy;
     p.B = B; p.N = N; p.heads = heads; p.M = M; p.clamp = clamp_temperature;
@@ -732,32 +745,27 @@ int pa2d_deslice_fwd(const float* xm, long long ldx, const float* o, const float
     p.ppc = ppc_for(N, p.nchunk);
     {
         const unsigned long long rows = (unsigned long long)B * N;
-        const unsigned long long xb = ((rows - 1) * ldx + (unsigned long long)heads * D) * 4ull;
-        const unsigned long long yb = ((rows - 1) * ldy + (unsigned long long)heads * D) * 4ull;
+        const unsigned long long xb = ((rows - 1) * ldx + (unsigned long long)heads * D) * es;
+        const unsigned long long yb = ((rows - 1) * ldy + (unsigned long long)heads * D) * es;
         if (xb >= 0xFFFFFFF0ull || yb >= 0xFFFFFFF0ull) return PA2D_ERR_UNSUPPORTED;
         p.x_bytes = (unsigned)xb; p.y_bytes = (unsigned)yb;
     }
     const int grid = B * heads * p.nchunk;
     if (ev_start && hipEventRecord(ev_start, st) != hipSuccess) return PA2D_ERR_ARG;
-#define CALL_DS(D_, MT_) launch_deslice_t<D_, MT_>(p, grid, st)
+#define CALL_DS(D_, MT_) launch_deslice_t<D_, MT_>(p, grid, st, bf)
     DISPATCH_D(CALL_DS)
     PA2D_CHECK_LAUNCH();
     if (ev_stop && hipEventRecord(ev_stop, st) != hipSuccess) return PA2D_ERR_ARG;
     return PA2D_OK;
 }
 
-size_t pa2d_slice_bwd_workspace(int B, int N, int heads, int D, int M) {
-    const int nchunk = pa2d_slice_nchunk(B, N, heads);
-    return sizeof(float) * ((size_t)B * heads * nchunk + 1) * ((size_t)M * D + M + 1);
-}
-
 // Backward phase C.  dws [M,D], dbs [M], dtemperature [heads] are fully reduced on return.
-int pa2d_slice_bwd_points(const float* xm, long long ldx, const float* fm, long long ldf, const float* dy,
-                          long long lddy, const float* ws, const float* bs, const float* temperature,
-                          const float* o, const float* ds, const float* dn, float* dxm, long long lddx, float* dfm,
-                          long long lddf, float* dws, float* dbs, float* dtemperature, void* ws_buf, size_t ws_bytes,
-                          int B, int N, int heads, int D, int M, int clamp_temperature, int accumulate, hipStream_t st,
-                          hipEvent_t ev_start, hipEvent_t ev_stop) {
+static int slice_bwd_impl(const void* xm, long long ldx, const void* fm, long long ldf, const void* dy, long long lddy,
+                          const float* ws, const float* bs, const float* temperature, const float* o, const float* ds,
+                          const float* dn, void* dxm, long long lddx, void* dfm, long long lddf, float* dws, float* dbs,
+                          float* dtemperature, void* ws_buf, size_t ws_bytes, int B, int N, int heads, int D, int M,
+                          int clamp_temperature, int accumulate, hipStream_t st, hipEvent_t ev_start,
+                          hipEvent_t ev_stop, bool bf) {
     const int mt = mt_for(M);
     if ((ldx & 3) || (ldf & 3) || (lddy & 3) || (lddx & 3) || (lddf & 3) || (D & 7)) return PA2D_ERR_ARG;
     if (B <= 0 || N <= 0) {
@@ -767,6 +775,7 @@ int pa2d_slice_bwd_points(const float* xm, long long ldx, const float* fm, long 
         return rz ? rz : pa2d_zero(dtemperature, sizeof(float) * heads, st);
     }
     if (ws_bytes < pa2d_slice_bwd_workspace(B, N, heads, D, M)) return PA2D_ERR_WORKSPACE;
+    const unsigned long long es = bf ? 2ull : 4ull;
     SliceBwdParams p;
     p.xm = xm; p.ldx = ldx; p.fm = fm; p.ldf = ldf; p.dy = dy; p.lddy = lddy; p.ws = ws; p.bs = bs;
     p.temperature = temperature; p.o = o; p.ds = ds; p.dn = dn; p.dxm = dxm; p.lddx = lddx; p.dfm = dfm;
@@ -775,9 +784,9 @@ int pa2d_slice_bwd_points(const float* xm, long long ldx, const float* fm, long 
     p.ppc = ppc_for(N, p.nchunk);
     {
         const unsigned long long rows = (unsigned long long)B * N, w = (unsigned long long)heads * D;
-        const unsigned long long e[5] = {((rows - 1) * ldx + w) * 4ull, ((rows - 1) * ldf + w) * 4ull,
-                                         ((rows - 1) * lddy + w) * 4ull, ((rows - 1) * lddx + w) * 4ull,
-                                         ((rows - 1) * lddf + w) * 4ull};
+        const unsigned long long e[5] = {((rows - 1) * ldx + w) * es, ((rows - 1) * ldf + w) * es,
+                                         ((rows - 1) * lddy + w) * es, ((rows - 1) * lddx + w) * es,
+                                         ((rows - 1) * lddf + w) * es};
         for (int i = 0; i < 5; ++i)
             if (e[i] >= 0xFFFFFFF0ull) return PA2D_ERR_UNSUPPORTED;
         p.x_bytes = (unsigned)e[0]; p.f_bytes = (unsigned)e[1]; p.dy_bytes = (unsigned)e[2];
@@ -786,7 +795,7 @@ int pa2d_slice_bwd_points(const float* xm, long long ldx, const float* fm, long 
     const int grid = B * heads * p.nchunk;
     int rc = PA2D_OK;
     if (ev_start && hipEventRecord(ev_start, st) != hipSuccess) return PA2D_ERR_ARG;
-#define CALL_BW(D_, MT_) rc = launch_bwd_t<D_, MT_>(p, grid, st)
+#define CALL_BW(D_, MT_) rc = launch_bwd_t<D_, MT_>(p, grid, st, bf)
     DISPATCH_D(CALL_BW)
     if (rc) return rc;
     PA2D_CHECK_LAUNCH();
@@ -804,6 +813,60 @@ int pa2d_slice_bwd_points(const float* xm, long long ldx, const float* fm, long 
                        dtemperature, B, heads, p.nchunk, stride, M * D + M, clamp_temperature, accumulate);
     PA2D_CHECK_LAUNCH();
     return PA2D_OK;
+}
+
+int pa2d_slice_scatter(const float* xm, long long ldx, const float* v, long long ldv, const float* ws,
+                       const float* bs, const float* temperature, float* spart, float* npart, int B, int N,
+                       int heads, int D, int M, int clamp_temperature, hipStream_t st, hipEvent_t ev_start,
+                       hipEvent_t ev_stop) {
+    return slice_scatter_impl(xm, ldx, v, ldv, ws, bs, temperature, spart, npart, B, N, heads, D, M, clamp_temperature, st,
+                              ev_start, ev_stop, false);
+}
+int pa2d_slice_scatter_bf16(const void* xm, long long ldx, const void* v, long long ldv, const float* ws,
+                            const float* bs, const float* temperature, float* spart, float* npart, int B, int N,
+                            int heads, int D, int M, int clamp_temperature, hipStream_t st, hipEvent_t ev_start,
+                            hipEvent_t ev_stop) {
+    return slice_scatter_impl(xm, ldx, v, ldv, ws, bs, temperature, spart, npart, B, N, heads, D, M, clamp_temperature, st,
+                              ev_start, ev_stop, true);
+}
+
+int pa2d_deslice_fwd(const float* xm, long long ldx, const float* o, const float* ws, const float* bs,
+                     const float* temperature, float* y, long long ldy, int B, int N, int heads, int D, int M,
+                     int clamp_temperature, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    return deslice_impl(xm, ldx, o, ws, bs, temperature, y, ldy, B, N, heads, D, M, clamp_temperature, st, ev_start, ev_stop,
+                        false);
+}
+int pa2d_deslice_fwd_bf16(const void* xm, long long ldx, const float* o, const float* ws, const float* bs,
+                          const float* temperature, void* y, long long ldy, int B, int N, int heads, int D, int M,
+                          int clamp_temperature, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    return deslice_impl(xm, ldx, o, ws, bs, temperature, y, ldy, B, N, heads, D, M, clamp_temperature, st, ev_start, ev_stop,
+                        true);
+}
+
+size_t pa2d_slice_bwd_workspace(int B, int N, int heads, int D, int M) {
+    const int nchunk = pa2d_slice_nchunk(B, N, heads);
+    return sizeof(float) * ((size_t)B * heads * nchunk + 1) * ((size_t)M * D + M + 1);
+}
+
+int pa2d_slice_bwd_points(const float* xm, long long ldx, const float* fm, long long ldf, const float* dy,
+                          long long lddy, const float* ws, const float* bs, const float* temperature,
+                          const float* o, const float* ds, const float* dn, float* dxm, long long lddx, float* dfm,
+                          long long lddf, float* dws, float* dbs, float* dtemperature, void* ws_buf, size_t ws_bytes,
+                          int B, int N, int heads, int D, int M, int clamp_temperature, int accumulate, hipStream_t st,
+                          hipEvent_t ev_start, hipEvent_t ev_stop) {
+    return slice_bwd_impl(xm, ldx, fm, ldf, dy, lddy, ws, bs, temperature, o, ds, dn, dxm, lddx, dfm, lddf, dws, dbs,
+                          dtemperature, ws_buf, ws_bytes, B, N, heads, D, M, clamp_temperature, accumulate, st, ev_start,
+                          ev_stop, false);
+}
+int pa2d_slice_bwd_points_bf16(const void* xm, long long ldx, const void* fm, long long ldf, const void* dy,
+                               long long lddy, const float* ws, const float* bs, const float* temperature,
+                               const float* o, const float* ds, const float* dn, void* dxm, long long lddx, void* dfm,
+                               long long lddf, float* dws, float* dbs, float* dtemperature, void* ws_buf,
+                               size_t ws_bytes, int B, int N, int heads, int D, int M, int clamp_temperature,
+                               int accumulate, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    return slice_bwd_impl(xm, ldx, fm, ldf, dy, lddy, ws, bs, temperature, o, ds, dn, dxm, lddx, dfm, lddf, dws, dbs,
+                          dtemperature, ws_buf, ws_bytes, B, N, heads, D, M, clamp_temperature, accumulate, st, ev_start,
+                          ev_stop, true);
 }
 
 }  // extern "C"

@@ -42,7 +42,10 @@ class FlatGradSync:
 
     ALIGN = 4       # floats: every slot starts on a 16-byte boundary (vector loads of the fused kernels)
 
-    def __init__(self, params, group=None):
+    def __init__(self, params, group=None, comm_dtype=None):
+        """`comm_dtype=torch.bfloat16`: the all-reduce moves a bf16 copy of the bucket (half the xGMI payload: 22.5 MB
+        instead of 45 MB at C=256); accumulation into the bucket and the optimizer stay fp32."""
+        self.comm_dtype = comm_dtype
         self.params = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("FlatGradSync needs at least one trainable parameter")
@@ -139,12 +142,19 @@ class FlatGradSync:
     def __call__(self):
         self.adopt()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            if self.comm_dtype is not None and self.comm_dtype != self.flat.dtype:
+                wire = self.flat.to(self.comm_dtype)
+                dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group)
+                self.flat.copy_(wire)
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
         self.release_untouched()
 
     @property
     def nbytes(self):
-        return self.flat.numel() * self.flat.element_size()
+        """bytes one all-reduce moves"""
+        es = self.flat.element_size() if self.comm_dtype is None else torch.empty(0, dtype=self.comm_dtype).element_size()
+        return self.flat.numel() * es
 
 
 def broadcast_parameters(module, src=0, group=None):

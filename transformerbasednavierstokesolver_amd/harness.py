@@ -87,8 +87,11 @@ def _fold_group(model, bsz, npoints, ncalls):
     r = max((blk.mlp.linear_pre[0].weight.shape[0] for blk in inner.blocks), default=C) / C
     width = int(max(2, r) * C)
     row_bytes = 4 * width
-    if model_engine(model) == ops.ENGINE_SPLIT:      # split engine: the 2C-wide conv gradient travels as 3 bf16 planes
+    eng = model_engine(model)
+    if eng == ops.ENGINE_SPLIT:      # split engine: the 2C-wide conv gradient travels as 3 bf16 planes
         row_bytes = max(row_bytes, 6 * 2 * C)
+    elif eng == ops.ENGINE_BF16S:    # bf16 storage: block activations are 2 bytes wide, the fp32 input embedding (2C) is not
+        row_bytes = max(2 * width, 4 * 2 * C)
     rows = FOLD_MAX_BYTES // row_bytes
     return max(1, min(ncalls, rows // max(1, bsz * npoints)))
 

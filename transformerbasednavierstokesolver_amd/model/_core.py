@@ -87,8 +87,8 @@ class BlockBase(nn.Module):
             return fx
         z = Fn.layer_norm(fx, self.ln_3.weight, self.ln_3.bias)
         if self.mlp2.out_features <= HEAD_KERNEL_MAX_OUT:
-            return Fn.head(z, self.mlp2.weight, self.mlp2.bias)
-        return Fn.linear(z, self.mlp2.weight, self.mlp2.bias, None, engine=self.engine)
+            return Fn.head(z, self.mlp2.weight, self.mlp2.bias)          # fp32 out, whatever the storage type
+        return Fn.linear(z, self.mlp2.weight, self.mlp2.bias, None, engine=self.engine).float()
 
 
 class TransolverBase(nn.Module):
@@ -140,6 +140,11 @@ class TransolverBase(nn.Module):
         return self
 
     def _run_blocks(self, z):
+        from .. import ops
+        if self.engine == ops.ENGINE_BF16S:
+            # bf16 storage: from here on every activation, saved tensor and inter-kernel gradient is bf16 (the cast is
+            # the one fp32 -> bf16 boundary; its autograd node casts the gradient back for the fp32 input embedding)
+            z = z.to(torch.bfloat16)
         for block in self.blocks:
             z = block(z)
         return z

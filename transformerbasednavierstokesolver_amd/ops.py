@@ -32,10 +32,18 @@ def _events(kind):
 # GEMM engines (include/pa2d.h: enum pa2d_engine).  The engine is an explicit argument of every dense op; `None`
 # means pa2d_default_engine() (env PA2D_GEMM=f32|split|bf16, else the fp32-accurate split engine).
 ENGINE_F32, ENGINE_SPLIT, ENGINE_BF16 = 0, 1, 2
-ENGINE_NAMES = {"f32": ENGINE_F32, "split": ENGINE_SPLIT, "bf16": ENGINE_BF16}
+# bf16 STORAGE (BASELINE configs[2] / [4] as stated): not an engine id of the C ABI but a host-side mode — the blocks'
+# activations, saved tensors and inter-kernel gradients are torch.bfloat16 tensors, and every op below dispatches on the
+# activation dtype to the *_bf16 entry points (one-term bf16 MFMA, fp32 accumulate, fp32 parameters / statistics).
+# fp32-in/fp32-out calls made by a model in this mode (the input embedding) run on ENGINE_BF16.
+ENGINE_BF16S = 3
+ENGINE_NAMES = {"f32": ENGINE_F32, "split": ENGINE_SPLIT, "bf16": ENGINE_BF16, "bf16s": ENGINE_BF16S}
 
 
 def default_engine():
+    import os
+    if os.environ.get("PA2D_GEMM", "") == "bf16s":      # host-side mode (see ENGINE_BF16S), not an ABI engine
+        return ENGINE_BF16S
     return _L().pa2d_default_engine()
 
 
@@ -44,9 +52,15 @@ def resolve_engine(engine):
         return default_engine()
     if isinstance(engine, str):
         return ENGINE_NAMES[engine]
-    if engine not in (ENGINE_F32, ENGINE_SPLIT, ENGINE_BF16):
+    if engine not in (ENGINE_F32, ENGINE_SPLIT, ENGINE_BF16, ENGINE_BF16S):
         raise ValueError(f"unknown GEMM engine {engine!r}")
     return int(engine)
+
+
+def _abi_engine(engine):
+    """Engine id for an fp32-I/O entry point of the C ABI (bf16-storage models run those on the bf16-compute engine)."""
+    eng = resolve_engine(engine)
+    return ENGINE_BF16 if eng == ENGINE_BF16S else eng
 
 
 def _L():
@@ -69,8 +83,30 @@ def _chk(*ts):
             raise ValueError("libpa2d ops need contiguous tensors")
 
 
-def _p(t, offset_floats=0):
-    return 0 if t is None else t.data_ptr() + 4 * offset_floats
+def _chk_act(*ts):
+    """Activation tensors: contiguous GPU fp32 or bf16, all of ONE dtype.  Returns True for bf16 storage."""
+    dt = None
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError("libpa2d ops need tensors on the GPU (no CPU fallback exists in this package)")
+        if t.dtype not in (torch.float32, torch.bfloat16):
+            raise TypeError(f"libpa2d activations are fp32 or bf16; got {t.dtype}")
+        if dt is not None and t.dtype != dt:
+            raise TypeError(f"activation tensors of one op must share a storage type; got {dt} and {t.dtype}")
+        dt = t.dtype
+        if not t.is_contiguous():
+            raise ValueError("libpa2d ops need contiguous tensors")
+    return dt == torch.bfloat16
+
+
+def _p(t, offset_elems=0):
+    return 0 if t is None else t.data_ptr() + t.element_size() * offset_elems
+
+
+def _fn(name, bf):
+    return getattr(_L(), name + "_bf16" if bf else name)
 
 
 def _ws(nbytes, like):
@@ -92,59 +128,71 @@ def _grad_outputs(into, shapes, like):
 
 # ----------------------------------------------------------------------------------------------
 def layernorm_fwd(x2d, gamma, beta, eps=LN_EPS):
-    _chk(x2d, gamma, beta)
+    _chk(gamma, beta)
+    bf = _chk_act(x2d)
     rows, Cc = x2d.shape
     y = torch.empty_like(x2d)
     mean = torch.empty(rows, dtype=torch.float32, device=x2d.device)
     rstd = torch.empty_like(mean)
-    _lib.check(_L().pa2d_layernorm_fwd(_p(x2d), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, Cc, eps,
+    _lib.check(_fn("pa2d_layernorm_fwd", bf)(_p(x2d), _p(gamma), _p(beta), _p(y), _p(mean), _p(rstd), rows, Cc, eps,
                                        _stream()), "layernorm_fwd")
     return y, mean, rstd
 
 
 def layernorm_bwd(dy, x2d, mean, rstd, gamma, dres=None, into=None):
-    _chk(dy, x2d, mean, rstd, gamma, dres)
+    _chk(mean, rstd, gamma)
+    bf = _chk_act(dy, x2d, dres)
     rows, Cc = x2d.shape
     dx = torch.empty_like(x2d)
     (dg, db), acc = _grad_outputs(into, (gamma.shape, gamma.shape), x2d)
     nb = _L().pa2d_layernorm_bwd_workspace(rows, Cc)
     ws = _ws(nb, x2d)
-    _lib.check(_L().pa2d_layernorm_bwd(_p(dy), _p(x2d), _p(mean), _p(rstd), _p(gamma), _p(dres), _p(dx), _p(dg),
+    _lib.check(_fn("pa2d_layernorm_bwd", bf)(_p(dy), _p(x2d), _p(mean), _p(rstd), _p(gamma), _p(dres), _p(dx), _p(dg),
                                        _p(db), ws.data_ptr(), nb, rows, Cc, acc, _stream()), "layernorm_bwd")
     return dx, dg, db
 
 
 def linear_fwd(x2d, w, bias=None, res=None, act=None, want_pre=False, engine=None):
     """y = act(x . w^T + bias) (+ res); returns (y, pre) with pre = pre-activation if want_pre."""
-    _chk(x2d, w, bias, res)
+    _chk(w, bias)
+    bf = _chk_act(x2d, res)
     M, K = x2d.shape
     N = w.shape[0]
-    y = torch.empty(M, N, dtype=torch.float32, device=x2d.device)
+    y = torch.empty(M, N, dtype=x2d.dtype, device=x2d.device)
     pre = torch.empty_like(y) if want_pre else None
-    _lib.check(_L().pa2d_gemm_bias_act_fwd(_p(x2d), K, _p(w), w.shape[1], _p(bias), _p(res), N, _p(y), N, _p(pre), N,
-                                           M, N, K, ACT_IDS[act], resolve_engine(engine), _stream()),
-               "gemm_bias_act_fwd")
+    if bf:
+        _lib.check(_L().pa2d_gemm_bias_act_fwd_bf16(_p(x2d), K, _p(w), w.shape[1], _p(bias), _p(res), N, _p(y), N,
+                                                    _p(pre), N, M, N, K, ACT_IDS[act], _stream()), "gemm_bias_act_fwd_bf16")
+    else:
+        _lib.check(_L().pa2d_gemm_bias_act_fwd(_p(x2d), K, _p(w), w.shape[1], _p(bias), _p(res), N, _p(y), N, _p(pre), N,
+                                               M, N, K, ACT_IDS[act], _abi_engine(engine), _stream()),
+                   "gemm_bias_act_fwd")
     return y, pre
 
 
 def linear_bwd_data(dy, w, pre=None, act=None, engine=None):
     """dx = (dy . w) * act'(pre)."""
-    _chk(dy, w, pre)
+    _chk(w)
+    bf = _chk_act(dy, pre)
     M, N = dy.shape
     K = w.shape[1]
-    dx = torch.empty(M, K, dtype=torch.float32, device=dy.device)
+    dx = torch.empty(M, K, dtype=dy.dtype, device=dy.device)
     wt = torch.empty(K * N, dtype=torch.float32, device=dy.device)
-    _lib.check(_L().pa2d_gemm_bwd_data(_p(dy), N, _p(w), K, _p(pre), K, ACT_IDS[act], _p(dx), K, _p(wt), M, N, K,
-                                       resolve_engine(engine), _stream()), "gemm_bwd_data")
+    if bf:
+        _lib.check(_L().pa2d_gemm_bwd_data_bf16(_p(dy), N, _p(w), K, _p(pre), K, ACT_IDS[act], _p(dx), K, _p(wt), M, N, K,
+                                                _stream()), "gemm_bwd_data_bf16")
+    else:
+        _lib.check(_L().pa2d_gemm_bwd_data(_p(dy), N, _p(w), K, _p(pre), K, ACT_IDS[act], _p(dx), K, _p(wt), M, N, K,
+                                           _abi_engine(engine), _stream()), "gemm_bwd_data")
     return dx
 
 
 def linear_bwd_weight(dy, x2d, want_bias=True, engine=None, into=None):
     """dw [N,K], db [N] (None if not wanted).  `into` = (dw_buffer, db_buffer or None): accumulate."""
-    _chk(dy, x2d)
+    bf = _chk_act(dy, x2d)
     M, N = dy.shape
     K = x2d.shape[1]
-    eng = resolve_engine(engine)
+    eng = _abi_engine(engine)
     if into is not None:
         dw, db = into
         _chk(dw, db)
@@ -157,6 +205,12 @@ def linear_bwd_weight(dy, x2d, want_bias=True, engine=None, into=None):
         dw = torch.empty(N, K, dtype=torch.float32, device=dy.device)
         db = torch.empty(N, dtype=torch.float32, device=dy.device) if want_bias else None
         acc = 0
+    if bf:
+        nb = _L().pa2d_gemm_bwd_weight_workspace_bf16(M, N, K)
+        ws = _ws(nb, dy)
+        _lib.check(_L().pa2d_gemm_bwd_weight_bf16(_p(dy), N, _p(x2d), K, _p(dw), _p(db), ws.data_ptr(), nb, M, N, K, acc,
+                                                  _stream()), "gemm_bwd_weight_bf16")
+        return dw, db
     nb = _L().pa2d_gemm_bwd_weight_workspace(M, N, K, eng)
     ws = _ws(nb, dy)
     _lib.check(_L().pa2d_gemm_bwd_weight(_p(dy), N, _p(x2d), K, _p(dw), _p(db), ws.data_ptr(), nb, M, N, K, acc, eng,
@@ -217,14 +271,21 @@ def _conv_pack(wx, wf, B, H, W, Cc, direction, eng):
 
 def conv3x3x2_fwd(xn, wx, bx, wf, bf, H, W, engine=None):
     """xn [B,N,C] -> [B,N,2C] = [x_mid | fx_mid]."""
-    _chk(xn, wx, bx, wf, bf)
+    _chk(wx, bx, wf, bf)
+    b16 = _chk_act(xn)
     B, N, Cc = xn.shape
-    eng = resolve_engine(engine)
-    out = torch.empty(B, N, 2 * Cc, dtype=torch.float32, device=xn.device)
+    eng = ENGINE_BF16 if b16 else _abi_engine(engine)
+    out = torch.empty(B, N, 2 * Cc, dtype=xn.dtype, device=xn.device)
     pre = _conv_pack(wx, wf, B, H, W, Cc, 0, eng)
+    e0, e1 = _events("conv")
+    if b16:
+        nb = _L().pa2d_conv3x3x2_fwd_workspace_bf16(B, H, W, Cc)
+        ws = _ws(nb, xn)
+        _lib.check(_L().pa2d_conv3x3x2_fwd_bf16(_p(xn), _p(wx), _p(bx), _p(wf), _p(bf), _p(out), pre, ws.data_ptr(), nb,
+                                                B, H, W, Cc, _stream(), e0, e1), "conv3x3x2_fwd_bf16")
+        return out
     nb = _L().pa2d_conv3x3x2_fwd_workspace(B, H, W, Cc, eng)
     ws = _ws(nb, xn)
-    e0, e1 = _events("conv")
     _lib.check(_L().pa2d_conv3x3x2_fwd(_p(xn), _p(wx), _p(bx), _p(wf), _p(bf), _p(out), pre, ws.data_ptr(), nb,
                                        B, H, W, Cc, eng, _stream(), e0, e1), "conv3x3x2_fwd")
     return out
@@ -232,15 +293,23 @@ def conv3x3x2_fwd(xn, wx, bx, wf, bf, H, W, engine=None):
 
 def conv3x3x2_bwd(dout, xn, wx, wf, H, W, need_dx=True, engine=None, into=None):
     """Returns (dxn, dwx, dbx, dwf, dbf); `into` = (dwx, dbx, dwf, dbf) buffers to accumulate into."""
-    _chk(dout, xn, wx, wf)
+    _chk(wx, wf)
+    b16 = _chk_act(dout, xn)
     B, N, Cc = xn.shape
-    eng = resolve_engine(engine)
+    eng = ENGINE_BF16 if b16 else _abi_engine(engine)
     dxn = torch.empty_like(xn) if need_dx else None
     (dwx, dbx, dwf, dbf), acc = _grad_outputs(into, (wx.shape, (Cc,), wf.shape, (Cc,)), xn)
-    nb = _L().pa2d_conv3x3x2_workspace(B, H, W, Cc, eng)
-    ws = _ws(nb, xn)
     pre = _conv_pack(wx, wf, B, H, W, Cc, 1, eng) if need_dx else 0
     e0, e1 = _events("conv") if need_dx else (0, 0)
+    if b16:
+        nb = _L().pa2d_conv3x3x2_workspace_bf16(B, H, W, Cc)
+        ws = _ws(nb, xn)
+        _lib.check(_L().pa2d_conv3x3x2_bwd_bf16(_p(dout), _p(xn), _p(wx), _p(wf), _p(dxn), _p(dwx), _p(dbx), _p(dwf),
+                                                _p(dbf), pre, ws.data_ptr(), nb, B, H, W, Cc, acc, _stream(), e0, e1),
+                   "conv3x3x2_bwd_bf16")
+        return dxn, dwx, dbx, dwf, dbf
+    nb = _L().pa2d_conv3x3x2_workspace(B, H, W, Cc, eng)
+    ws = _ws(nb, xn)
     _lib.check(_L().pa2d_conv3x3x2_bwd(_p(dout), _p(xn), _p(wx), _p(wf), _p(dxn), _p(dwx), _p(dbx), _p(dwf), _p(dbf),
                                        pre, ws.data_ptr(), nb, B, H, W, Cc, acc, eng, _stream(), e0, e1),
                "conv3x3x2_bwd")
@@ -254,12 +323,13 @@ def slice_nchunk(B, N, heads):
 def slice_scatter(xm, ldx, xm_off, v, ldv, v_off, ws_w, bs, temperature, B, N, heads, D, M, want_norm=True,
                   clamp=True):
     """Partial sums of W^T V per point chunk.  xm / v are base tensors; *_off are float offsets."""
-    _chk(xm, v, ws_w, bs, temperature)
+    _chk(ws_w, bs, temperature)
+    bf = _chk_act(xm, v)
     nchunk = slice_nchunk(B, N, heads)
     spart = torch.empty(B * heads, nchunk, M, D, dtype=torch.float32, device=xm.device)
     npart = torch.empty(B * heads, nchunk, M, dtype=torch.float32, device=xm.device) if want_norm else None
     e0, e1 = _events("slice_scatter")
-    _lib.check(_L().pa2d_slice_scatter(_p(xm, xm_off), ldx, _p(v, v_off), ldv, _p(ws_w), _p(bs), _p(temperature),
+    _lib.check(_fn("pa2d_slice_scatter", bf)(_p(xm, xm_off), ldx, _p(v, v_off), ldv, _p(ws_w), _p(bs), _p(temperature),
                                        _p(spart), _p(npart), B, N, heads, D, M, int(clamp), _stream(), e0, e1),
                "slice_scatter")
     return spart, npart
@@ -291,24 +361,26 @@ def token_attn_bwd(s, nrm, wq, wk, wv, dopart, into=None):
 
 
 def deslice_fwd(xm, ldx, xm_off, o, ws_w, bs, temperature, B, N, heads, D, M, clamp=True):
-    _chk(xm, o, ws_w, bs, temperature)
-    y = torch.empty(B, N, heads * D, dtype=torch.float32, device=xm.device)
+    _chk(o, ws_w, bs, temperature)
+    bf = _chk_act(xm)
+    y = torch.empty(B, N, heads * D, dtype=xm.dtype, device=xm.device)
     e0, e1 = _events("deslice")
-    _lib.check(_L().pa2d_deslice_fwd(_p(xm, xm_off), ldx, _p(o), _p(ws_w), _p(bs), _p(temperature), _p(y), heads * D,
+    _lib.check(_fn("pa2d_deslice_fwd", bf)(_p(xm, xm_off), ldx, _p(o), _p(ws_w), _p(bs), _p(temperature), _p(y), heads * D,
                                      B, N, heads, D, M, int(clamp), _stream(), e0, e1), "deslice_fwd")
     return y
 
 
 def slice_bwd_points(xf, dy, ws_w, bs, temperature, o, ds, dn, B, N, heads, D, M, clamp=True, into=None):
     """xf = [B,N,2C] ([x_mid | fx_mid]); returns dxf [B,N,2C], dws, dbs, dtemperature [heads]."""
-    _chk(xf, dy, ws_w, bs, temperature, o, ds, dn)
+    _chk(ws_w, bs, temperature, o, ds, dn)
+    bf = _chk_act(xf, dy)
     Cc = heads * D
     dxf = torch.empty_like(xf)
     (dws, dbs, dtemp), acc = _grad_outputs(into, (ws_w.shape, bs.shape, (heads,)), xf)
     nb = _L().pa2d_slice_bwd_workspace(B, N, heads, D, M)
     ws = _ws(nb, xf)
     e0, e1 = _events("slice_bwd")
-    _lib.check(_L().pa2d_slice_bwd_points(_p(xf), 2 * Cc, _p(xf, Cc), 2 * Cc, _p(dy), Cc, _p(ws_w), _p(bs),
+    _lib.check(_fn("pa2d_slice_bwd_points", bf)(_p(xf), 2 * Cc, _p(xf, Cc), 2 * Cc, _p(dy), Cc, _p(ws_w), _p(bs),
                                           _p(temperature), _p(o), _p(ds), _p(dn), _p(dxf), 2 * Cc, _p(dxf, Cc),
                                           2 * Cc, _p(dws), _p(dbs), _p(dtemp), ws.data_ptr(), nb, B, N, heads, D, M,
                                           int(clamp), acc, _stream(), e0, e1), "slice_bwd_points")
@@ -316,23 +388,26 @@ def slice_bwd_points(xf, dy, ws_w, bs, temperature, o, ds, dn, B, N, heads, D, M
 
 
 def head_fwd(xn2d, w, b):
-    _chk(xn2d, w, b)
+    """y is always fp32 (the model output), whatever the storage type of the activations."""
+    _chk(w, b)
+    bf = _chk_act(xn2d)
     rows, Cc = xn2d.shape
     O = w.shape[0]
     y = torch.empty(rows, O, dtype=torch.float32, device=xn2d.device)
-    _lib.check(_L().pa2d_head_fwd(_p(xn2d), _p(w), _p(b), _p(y), rows, Cc, O, _stream()), "head_fwd")
+    _lib.check(_fn("pa2d_head_fwd", bf)(_p(xn2d), _p(w), _p(b), _p(y), rows, Cc, O, _stream()), "head_fwd")
     return y
 
 
 def head_bwd(dy, xn2d, w, into=None):
-    _chk(dy, xn2d, w)
+    _chk(dy, w)
+    bf = _chk_act(xn2d)
     rows, Cc = xn2d.shape
     O = w.shape[0]
     dxn = torch.empty_like(xn2d)
     (dw, db), acc = _grad_outputs(into, (w.shape, (O,)), w)
     nb = _L().pa2d_head_bwd_workspace(rows, Cc, O)
     ws = _ws(nb, dy)
-    _lib.check(_L().pa2d_head_bwd(_p(dy), _p(xn2d), _p(w), _p(dxn), _p(dw), _p(db), ws.data_ptr(), nb, rows, Cc, O,
+    _lib.check(_fn("pa2d_head_bwd", bf)(_p(dy), _p(xn2d), _p(w), _p(dxn), _p(dw), _p(db), ws.data_ptr(), nb, rows, Cc, O,
                                   acc, _stream()), "head_bwd")
     return dxn, dw, db
 

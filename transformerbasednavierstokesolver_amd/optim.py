@@ -20,12 +20,14 @@ from .ddp import FlatGradSync
 
 
 class FusedAdamW(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=None):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=None,
+                 grad_comm_dtype=None):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         if len(self.param_groups) != 1:
             raise NotImplementedError("FusedAdamW supports a single parameter group")
         self.max_grad_norm = max_grad_norm
-        self.sync = FlatGradSync(self.param_groups[0]["params"])     # flat gradient bucket (+ all-reduce)
+        # flat gradient bucket (+ all-reduce; grad_comm_dtype=torch.bfloat16 halves its wire size)
+        self.sync = FlatGradSync(self.param_groups[0]["params"], comm_dtype=grad_comm_dtype)
         self.flat_p = torch.empty_like(self.sync.flat)
         with torch.no_grad():
             self.flat_p.zero_()
