@@ -362,7 +362,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8, help="trajectories of the CPU protocol iteration (config C1: 8)")
     ap.add_argument("--cpu-iters", type=int, default=3)
-    ap.add_argument("--cpu-budget-s", type=float, default=240.0, help="wall-clock budget of the CPU training iterations")
+    ap.add_argument("--cpu-budget-s", type=float, default=330.0, help="wall-clock budget of the CPU training iterations")
     ap.add_argument("--no-rollout", action="store_true")
     ap.add_argument("--graph", action="store_true",
                     help="replay forward+backward from one hipGraph (launch-bound small batches); disables the per-kernel HIP events")

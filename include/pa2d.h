@@ -184,8 +184,8 @@ int pa2d_rel_l2_bwd(const float* pred, const float* y, const float* dnorm, const
  * Same stages, same argument order as the fp32 entry points above, but every ACTIVATION pointer (inputs, outputs,
  * saved tensors, inter-kernel gradients: the `void*` arguments) holds bf16; parameters, biases, LayerNorm statistics,
  * slice partial sums / norms, token tensors and every parameter gradient stay fp32; all accumulation is fp32.  GEMMs
- * use ONE bf16 MFMA term (the arithmetic of PA2D_ENGINE_BF16; conv weight packs are made by pa2d_conv3x3x2_pack with
- * PA2D_ENGINE_BF16).  ld* are in elements.  Dense layers need K % 32 == 0 (and N, K % 32 == 0 for the weight
+ * use ONE bf16 MFMA term (the arithmetic of PA2D_ENGINE_BF16; conv weight packs are made by pa2d_conv3x3x2_pack_bf16).
+ * ld* are in elements.  Dense layers need K % 32 == 0 (and N, K % 32 == 0 for the weight
  * gradient, whose operands must be contiguous), the conv C % 32 == 0: otherwise PA2D_ERR_UNSUPPORTED. */
 int pa2d_layernorm_fwd_bf16(const void* x, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
                             int rows, int C, float eps, pa2d_stream_t stream);
@@ -201,6 +201,9 @@ int pa2d_gemm_bwd_data_bf16(const void* dy, long long lddy, const float* w, long
 size_t pa2d_gemm_bwd_weight_workspace_bf16(int M, int N, int K);
 int pa2d_gemm_bwd_weight_bf16(const void* dy, long long lddy, const void* x, long long ldx, float* dw, float* db,
                               void* ws, size_t ws_bytes, int M, int N, int K, int accumulate, pa2d_stream_t stream);
+/* weight pack for pa2d_conv3x3x2_{fwd,bwd}_bf16 (`prepacked`): pa2d_conv3x3x2_pack_bytes(C) bytes; direction as above */
+int pa2d_conv3x3x2_pack_bf16(const float* wx, const float* wf, void* pack, size_t pack_bytes, int C, int direction,
+                             pa2d_stream_t stream);
 size_t pa2d_conv3x3x2_workspace_bf16(int B, int H, int W, int C);       /* backward */
 size_t pa2d_conv3x3x2_fwd_workspace_bf16(int B, int H, int W, int C);   /* forward  */
 int pa2d_conv3x3x2_fwd_bf16(const void* xn, const float* wx, const float* bx, const float* wf, const float* bf,

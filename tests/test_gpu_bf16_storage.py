@@ -106,6 +106,11 @@ def test_conv_bf16(monkeypatch, B, H, W, C, policy):
     ops.conv3x3x2_bwd(dout, xn, g(wx), g(wf), H, W, need_dx=False, into=into)
     for got, ref in zip(into, (dwx, dbx, dwf, dbf)):
         assert rel_l2(got - 0.125, ref) < 1e-5
+    # inside a weights_frozen scope the calls run from PRE-MADE packs (narrow shapes included): same results bit for bit
+    with ops.weights_frozen():
+        for _ in range(2):
+            assert torch.equal(ops.conv3x3x2_fwd(xn, g(wx), g(bx), g(wf), g(bf), H, W), out)
+            assert torch.equal(ops.conv3x3x2_bwd(dout, xn, g(wx), g(wf), H, W)[0], dxn)
 
 
 @pytest.mark.parametrize("B,N,heads,D,M", [(2, 30, 4, 8, 12), (2, 4096, 8, 32, 64), (1, 1000, 8, 16, 128)])

@@ -67,6 +67,7 @@ SIGNATURES.update({
     "pa2d_gemm_bwd_data_bf16": (_i, [_f, _ll, _f, _ll, _f, _ll, _i, _f, _ll, _f, _i, _i, _i, _st]),
     "pa2d_gemm_bwd_weight_workspace_bf16": (_sz, [_i, _i, _i]),
     "pa2d_gemm_bwd_weight_bf16": (_i, [_f, _ll, _f, _ll, _f, _f, _f, _sz, _i, _i, _i, _i, _st]),
+    "pa2d_conv3x3x2_pack_bf16": (_i, [_f, _f, _f, _sz, _i, _i, _st]),
     "pa2d_conv3x3x2_workspace_bf16": (_sz, [_i, _i, _i, _i]),
     "pa2d_conv3x3x2_fwd_workspace_bf16": (_sz, [_i, _i, _i, _i]),
     "pa2d_conv3x3x2_fwd_bf16": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _i, _st, _st, _st]),

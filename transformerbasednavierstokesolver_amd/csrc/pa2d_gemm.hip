@@ -386,6 +386,15 @@ int pa2d_gemm_bwd_weight_bf16(const void* dy, long long lddy, const void* x, lon
     return rc;
 }
 
+// weight pack of the bf16-storage conv: ALWAYS the 1-plane bf16 K-step image (these entry points use the bf16 kernels
+// for every shape, also the narrow ones the fp32-I/O engines hand to the exact kernel)
+int pa2d_conv3x3x2_pack_bf16(const float* wx, const float* wf, void* pack, size_t pack_bytes, int C, int direction,
+                             hipStream_t st) {
+    if (C & 31) return PA2D_ERR_UNSUPPORTED;
+    if (pack_bytes < pa2d_conv3x3x2_pack_bytes(C)) return PA2D_ERR_WORKSPACE;
+    return launch_repack_split(wx, wf, pack, direction ? 1 : 0, 1, C, C, st);
+}
+
 size_t pa2d_conv3x3x2_fwd_workspace_bf16(int B, int H, int W, int C) {
     (void)B; (void)H; (void)W;
     return pa2d_conv3x3x2_pack_bytes(C);

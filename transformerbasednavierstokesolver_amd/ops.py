@@ -231,8 +231,7 @@ class _FrozenScope:
         """Re-pack every entry in place (same device pointers): called before replaying a hipGraph that was captured
         inside this scope, so the graph's conv launches always see the current weights."""
         for (_, _, B, H, W, Cc, direction, eng), (wx, wf, pack) in self.packs.items():
-            _lib.check(_L().pa2d_conv3x3x2_pack(_p(wx), _p(wf), pack.data_ptr(), pack.numel(), B, H, W, Cc, direction,
-                                                eng, _stream()), "conv3x3x2_pack")
+            _make_pack(wx, wf, pack, B, H, W, Cc, direction, eng)
 
 
 _frozen = []      # stack of active scopes
@@ -253,6 +252,16 @@ class weights_frozen:
         return False
 
 
+def _make_pack(wx, wf, pack, B, H, W, Cc, direction, eng):
+    """eng = ENGINE_BF16S: the pack of the bf16-storage conv entry points (always the bf16 kernels' layout)."""
+    if eng == ENGINE_BF16S:
+        _lib.check(_L().pa2d_conv3x3x2_pack_bf16(_p(wx), _p(wf), pack.data_ptr(), pack.numel(), Cc, direction, _stream()),
+                   "conv3x3x2_pack_bf16")
+    else:
+        _lib.check(_L().pa2d_conv3x3x2_pack(_p(wx), _p(wf), pack.data_ptr(), pack.numel(), B, H, W, Cc, direction, eng,
+                                            _stream()), "conv3x3x2_pack")
+
+
 def _conv_pack(wx, wf, B, H, W, Cc, direction, eng):
     """Pack pointer for the active scope (0 = let the conv call pack into its workspace)."""
     if not _frozen:
@@ -263,8 +272,7 @@ def _conv_pack(wx, wf, B, H, W, Cc, direction, eng):
     if hit is None:
         nb = _L().pa2d_conv3x3x2_pack_bytes(Cc)
         pack = torch.empty(nb, dtype=torch.uint8, device=wx.device)
-        _lib.check(_L().pa2d_conv3x3x2_pack(_p(wx), _p(wf), pack.data_ptr(), nb, B, H, W, Cc, direction, eng,
-                                            _stream()), "conv3x3x2_pack")
+        _make_pack(wx, wf, pack, B, H, W, Cc, direction, eng)
         hit = scope.packs[key] = (wx, wf, pack)
     return hit[2].data_ptr()
 
@@ -274,7 +282,7 @@ def conv3x3x2_fwd(xn, wx, bx, wf, bf, H, W, engine=None):
     _chk(wx, bx, wf, bf)
     b16 = _chk_act(xn)
     B, N, Cc = xn.shape
-    eng = ENGINE_BF16 if b16 else _abi_engine(engine)
+    eng = ENGINE_BF16S if b16 else _abi_engine(engine)
     out = torch.empty(B, N, 2 * Cc, dtype=xn.dtype, device=xn.device)
     pre = _conv_pack(wx, wf, B, H, W, Cc, 0, eng)
     e0, e1 = _events("conv")
@@ -296,7 +304,7 @@ def conv3x3x2_bwd(dout, xn, wx, wf, H, W, need_dx=True, engine=None, into=None):
     _chk(wx, wf)
     b16 = _chk_act(dout, xn)
     B, N, Cc = xn.shape
-    eng = ENGINE_BF16 if b16 else _abi_engine(engine)
+    eng = ENGINE_BF16S if b16 else _abi_engine(engine)
     dxn = torch.empty_like(xn) if need_dx else None
     (dwx, dbx, dwf, dbf), acc = _grad_outputs(into, (wx.shape, (Cc,), wf.shape, (Cc,)), xn)
     pre = _conv_pack(wx, wf, B, H, W, Cc, 1, eng) if need_dx else 0
