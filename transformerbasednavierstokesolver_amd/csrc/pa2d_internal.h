@@ -191,3 +191,31 @@ template <> struct Act<bf16_t> {
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc_v(const void* base, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
 }
+
+// Workgroup -> (batch, head, point chunk) of the slice-stage kernels.  xcd_map = 1: workgroups are numbered so that each
+// XCD (blockIdx & 7 under round-robin dispatch) owns a CONTIGUOUS range with the head index fastest: the `heads`
+// workgroups that read the 128-byte head segments of the SAME activation rows run next to each other behind one L2, so
+// HBM sees whole rows instead of eight interleaved strided streams.  xcd_map = 0: legacy order (chunk fastest).
+// bid = index of the workgroup's partial-sum record, independent of the map.  Launch with slice_grid(total) blocks.
+__device__ __forceinline__ bool slice_decode(int xcd_map, int B, int heads, int nchunk, int& b, int& hh, int& chunk, int& bid) {
+    const int total = B * heads * nchunk;
+    int L;
+    if (xcd_map) {
+        const int per = (total + 7) >> 3;
+        if ((int)(blockIdx.x >> 3) >= per) return false;
+        L = (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3);
+        if (L >= total) return false;
+        hh = L % heads;
+        chunk = (L / heads) % nchunk;
+        b = L / (heads * nchunk);
+    } else {
+        L = (int)blockIdx.x;
+        if (L >= total) return false;
+        chunk = L % nchunk;
+        hh = (L / nchunk) % heads;
+        b = L / (nchunk * heads);
+    }
+    bid = (b * heads + hh) * nchunk + chunk;
+    return true;
+}
+static inline int slice_grid(int total) { return ((total + 7) / 8) * 8; }

@@ -16,6 +16,7 @@
 // X / F / dY fragments are loaded straight from global memory (each element exactly once, 64-B
 // contiguous per point per instruction); no LDS in the forward kernels.
 #include "pa2d_internal.h"
+#include <stdlib.h>
 
 #define NEG_BIG (-1e30f)
 
@@ -111,6 +112,7 @@ struct SliceParams {
     int B, N, heads, M, nchunk, ppc;    // ppc = points per chunk (multiple of 16)
     unsigned x_bytes, v_bytes;          // extents for the buffer descriptors
     int clamp;                          // 1: clamp(temperature, .1, 5) (structured mesh); 0: raw (irregular mesh)
+    int xcd_map;                        // workgroup numbering, see slice_decode
 };
 
 // S_partial[m][d] = sum_{n in chunk} W[n][m] * V[n][d];  n_partial[m] = sum_n W[n][m]
@@ -122,9 +124,8 @@ __global__ __launch_bounds__(256) void slice_scatter_kernel(const SliceParams p)
     __shared__ float sbuf[MP * DP];
     __shared__ float nbuf[MP];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
-    const int chunk = blockIdx.x % p.nchunk;
-    const int hh = (blockIdx.x / p.nchunk) % p.heads;
-    const int b = blockIdx.x / (p.nchunk * p.heads);
+    int b, hh, chunk, bid;
+    if (!slice_decode(p.xcd_map, p.B, p.heads, p.nchunk, b, hh, chunk, bid)) return;
     const float inv_tau = 1.0f / (p.clamp ? clamp_tau(p.temperature[hh]) : p.temperature[hh]);
 
     float wsf[MT][KS], bsv[MT];
@@ -233,10 +234,10 @@ __global__ __launch_bounds__(256) void slice_scatter_kernel(const SliceParams p)
         }
         __syncthreads();
     }
-    float* so = p.spart + (size_t)blockIdx.x * p.M * D;
+    float* so = p.spart + (size_t)bid * p.M * D;
     for (int i = tid; i < p.M * D; i += 256) so[i] = sbuf[(i / D) * DP + (i % D)];
     if (p.npart)
-        for (int i = tid; i < p.M; i += 256) p.npart[(size_t)blockIdx.x * p.M + i] = nbuf[i];
+        for (int i = tid; i < p.M; i += 256) p.npart[(size_t)bid * p.M + i] = nbuf[i];
 }
 
 struct DesliceParams {
@@ -246,7 +247,7 @@ struct DesliceParams {
     void* y; long long ldy;             // y[(b*N+n)*ldy + h*D + d]
     int B, N, heads, M, nchunk, ppc;
     unsigned x_bytes, y_bytes;
-    int clamp;
+    int clamp, xcd_map;
 };
 
 // Y[n][h*D+d] = sum_m W[n][m] * O[m][d]
@@ -255,9 +256,8 @@ __global__ __launch_bounds__(256) void deslice_kernel(const DesliceParams p) {
     constexpr int KS = SCfg<D>::KS, DT = SCfg<D>::DT;
     constexpr unsigned ES = Act<T>::ES;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
-    const int chunk = blockIdx.x % p.nchunk;
-    const int hh = (blockIdx.x / p.nchunk) % p.heads;
-    const int b = blockIdx.x / (p.nchunk * p.heads);
+    int b, hh, chunk, bid;
+    if (!slice_decode(p.xcd_map, p.B, p.heads, p.nchunk, b, hh, chunk, bid)) return;
     const float inv_tau = 1.0f / (p.clamp ? clamp_tau(p.temperature[hh]) : p.temperature[hh]);
 
     float wsf[MT][KS], bst[MT][4], of[MT][4][DT];
@@ -350,7 +350,7 @@ struct SliceBwdParams {
     float* part;                        // per block: [M*D (dWs) | M (dbs) | 1 (dtau)]
     int B, N, heads, M, nchunk, ppc;
     unsigned x_bytes, f_bytes, dy_bytes, dx_bytes, df_bytes;
-    int clamp;
+    int clamp, xcd_map;
 };
 
 // Backward phase C (per point): recompute W, then
@@ -373,9 +373,8 @@ __global__ __launch_bounds__(256) void slice_bwd_kernel(const SliceBwdParams p) 
                                              // fragment matrices (dead after the point loop)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
-    const int chunk = blockIdx.x % p.nchunk;
-    const int hh = (blockIdx.x / p.nchunk) % p.heads;
-    const int b = blockIdx.x / (p.nchunk * p.heads);
+    int b, hh, chunk, bid;
+    if (!slice_decode(p.xcd_map, p.B, p.heads, p.nchunk, b, hh, chunk, bid)) return;
     const float inv_tau = 1.0f / (p.clamp ? clamp_tau(p.temperature[hh]) : p.temperature[hh]);
     const size_t bh = (size_t)(b * p.heads + hh);
 
@@ -604,7 +603,7 @@ __global__ __launch_bounds__(256) void slice_bwd_kernel(const SliceBwdParams p) 
         }
         __syncthreads();
     }
-    float* po = p.part + (size_t)blockIdx.x * (p.M * D + p.M + 1);
+    float* po = p.part + (size_t)bid * (p.M * D + p.M + 1);
     for (int i = tid; i < p.M * D; i += 256) po[i] = rW[(i / D) * DP + (i % D)] * inv_tau;
     for (int i = tid; i < p.M; i += 256) po[p.M * D + i] = rB[i] * inv_tau;
     if (tid == 0) po[p.M * D + p.M] = -rT[0] * inv_tau;
@@ -628,13 +627,13 @@ __global__ void dtau_finalize_kernel(const float* __restrict__ part, const float
 // dispatch over the compile-time (D, MT) grid
 template <int D, int MT>
 static void launch_scatter_t(const SliceParams& p, int grid, hipStream_t st, bool bf) {
-    if (bf) hipLaunchKernelGGL((slice_scatter_kernel<D, MT, bf16_t>), dim3(grid), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((slice_scatter_kernel<D, MT, float>), dim3(grid), dim3(256), 0, st, p);
+    if (bf) hipLaunchKernelGGL((slice_scatter_kernel<D, MT, bf16_t>), dim3(slice_grid(grid)), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((slice_scatter_kernel<D, MT, float>), dim3(slice_grid(grid)), dim3(256), 0, st, p);
 }
 template <int D, int MT>
 static void launch_deslice_t(const DesliceParams& p, int grid, hipStream_t st, bool bf) {
-    if (bf) hipLaunchKernelGGL((deslice_kernel<D, MT, bf16_t>), dim3(grid), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((deslice_kernel<D, MT, float>), dim3(grid), dim3(256), 0, st, p);
+    if (bf) hipLaunchKernelGGL((deslice_kernel<D, MT, bf16_t>), dim3(slice_grid(grid)), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((deslice_kernel<D, MT, float>), dim3(slice_grid(grid)), dim3(256), 0, st, p);
 }
 template <int D, int MT>
 static size_t bwd_smem_bytes() {
@@ -652,8 +651,8 @@ static int launch_bwd_t(const SliceBwdParams& p, int grid, hipStream_t st, bool 
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
         if (e != hipSuccess) return (int)e;
     }
-    if (bf) hipLaunchKernelGGL((slice_bwd_kernel<D, MT, bf16_t>), dim3(grid), dim3(256), smem, st, p);
-    else hipLaunchKernelGGL((slice_bwd_kernel<D, MT, float>), dim3(grid), dim3(256), smem, st, p);
+    if (bf) hipLaunchKernelGGL((slice_bwd_kernel<D, MT, bf16_t>), dim3(slice_grid(grid)), dim3(256), smem, st, p);
+    else hipLaunchKernelGGL((slice_bwd_kernel<D, MT, float>), dim3(slice_grid(grid)), dim3(256), smem, st, p);
     return PA2D_OK;
 }
 
@@ -699,6 +698,26 @@ int pa2d_slice_nchunk(int B, int N, int heads) {
     return ceil_div(N, ppc);
 }
 static int ppc_for(int N, int nchunk) { return ceil_div(ceil_div(N, nchunk), 16) * 16; }
+// bf16-MFMA forms of the forward kernels (pa2d_slice_bf.hip): the default; PA2D_SLICE_MFMA=f32 keeps the exact-fp32-MFMA
+// kernels of this file (A/B timing, and the reference the new ones are tested against)
+int pa2d_launch_scatter_bf(const void* xm, long long ldx, const void* v, long long ldv, const float* ws, const float* bs,
+                           const float* temperature, float* spart, float* npart, int B, int N, int heads, int D, int M,
+                           int mt, int nchunk, int ppc, unsigned x_bytes, unsigned v_bytes, int clamp, int xcd_map, bool bf,
+                           hipStream_t st);
+int pa2d_launch_deslice_bf(const void* xm, long long ldx, const float* o, const float* ws, const float* bs,
+                           const float* temperature, void* y, long long ldy, int B, int N, int heads, int D, int M, int mt,
+                           int nchunk, int ppc, unsigned x_bytes, unsigned y_bytes, int clamp, int xcd_map, bool bf, hipStream_t st);
+static int slice_xcd_map() {          // PA2D_SLICE_MAP=legacy keeps the chunk-fastest numbering (A/B timing)
+    const char* e = getenv("PA2D_SLICE_MAP");
+    return (e && e[0] == 'l') ? 0 : 1;
+}
+// PA2D_SLICE_MFMA=f32 forces the exact-fp32-MFMA kernels of this file; default: bf16 MFMA (measured at the bench shape,
+// fp32 storage: scatter 0.120 vs 0.131 ms, de-slice 0.098 vs 0.108 ms; bf16 storage: scatter 0.077 vs 0.120 ms)
+static bool slice_on_bf16_mfma(bool scatter, bool bf) {
+    (void)scatter; (void)bf;
+    const char* e = getenv("PA2D_SLICE_MFMA");
+    return !(e && e[0] == 'f');
+}
 size_t pa2d_slice_bwd_workspace(int B, int N, int heads, int D, int M);
 
 // spart [B,heads,nchunk,M,D], npart [B,heads,nchunk,M] (NULL to skip the norm); bf: activations stored as bf16
@@ -712,7 +731,7 @@ static int slice_scatter_impl(const void* xm, long long ldx, const void* v, long
     const unsigned long long es = bf ? 2ull : 4ull;
     SliceParams p;
     p.xm = xm; p.ldx = ldx; p.v = v; p.ldv = ldv; p.ws = ws; p.bs = bs; p.temperature = temperature;
-    p.spart = spart; p.npart = npart; p.B = B; p.N = N; p.heads = heads; p.M = M; p.clamp = clamp_temperature;
+    p.spart = spart; p.npart = npart; p.B = B; p.N = N; p.heads = heads; p.M = M; p.clamp = clamp_temperature; p.xcd_map = slice_xcd_map();
     p.nchunk = pa2d_slice_nchunk(B, N, heads);
     p.ppc = ppc_for(N, p.nchunk);
     {
@@ -724,8 +743,14 @@ static int slice_scatter_impl(const void* xm, long long ldx, const void* v, long
     }
     const int grid = B * heads * p.nchunk;
     if (ev_start && hipEventRecord(ev_start, st) != hipSuccess) return PA2D_ERR_ARG;
+    if (slice_on_bf16_mfma(true, bf)) {
+        const int rc = pa2d_launch_scatter_bf(xm, ldx, v, ldv, ws, bs, temperature, spart, npart, B, N, heads, D, M, mt,
+                                              p.nchunk, p.ppc, p.x_bytes, p.v_bytes, clamp_temperature, p.xcd_map, bf, st);
+        if (rc) return rc;
+    } else {
 #define CALL_SC(D_, MT_) launch_scatter_t<D_, MT_>(p, grid, st, bf)
-    DISPATCH_D(CALL_SC)
+        DISPATCH_D(CALL_SC)
+    }
     PA2D_CHECK_LAUNCH();
     if (ev_stop && hipEventRecord(ev_stop, st) != hipSuccess) return PA2D_ERR_ARG;
     return PA2D_OK;
@@ -740,7 +765,7 @@ static int deslice_impl(const void* xm, long long ldx, const float* o, const flo
     const unsigned long long es = bf ? 2ull : 4ull;
     DesliceParams p;
     p.xm = xm; p.ldx = ldx; p.o = o; p.ws = ws; p.bs = bs; p.temperature = temperature; p.y = y; p.ldy = ldy;
-    p.B = B; p.N = N; p.heads = heads; p.M = M; p.clamp = clamp_temperature;
+    p.B = B; p.N = N; p.heads = heads; p.M = M; p.clamp = clamp_temperature; p.xcd_map = slice_xcd_map();
     p.nchunk = pa2d_slice_nchunk(B, N, heads);
     p.ppc = ppc_for(N, p.nchunk);
     {
@@ -752,8 +777,14 @@ static int deslice_impl(const void* xm, long long ldx, const float* o, const flo
     }
     const int grid = B * heads * p.nchunk;
     if (ev_start && hipEventRecord(ev_start, st) != hipSuccess) return PA2D_ERR_ARG;
+    if (slice_on_bf16_mfma(false, bf)) {
+        const int rc = pa2d_launch_deslice_bf(xm, ldx, o, ws, bs, temperature, y, ldy, B, N, heads, D, M, mt, p.nchunk, p.ppc,
+                                              p.x_bytes, p.y_bytes, clamp_temperature, p.xcd_map, bf, st);
+        if (rc) return rc;
+    } else {
 #define CALL_DS(D_, MT_) launch_deslice_t<D_, MT_>(p, grid, st, bf)
-    DISPATCH_D(CALL_DS)
+        DISPATCH_D(CALL_DS)
+    }
     PA2D_CHECK_LAUNCH();
     if (ev_stop && hipEventRecord(ev_stop, st) != hipSuccess) return PA2D_ERR_ARG;
     return PA2D_OK;
@@ -780,6 +811,7 @@ static int slice_bwd_impl(const void* xm, long long ldx, const void* fm, long lo
     p.xm = xm; p.ldx = ldx; p.fm = fm; p.ldf = ldf; p.dy = dy; p.lddy = lddy; p.ws = ws; p.bs = bs;
     p.temperature = temperature; p.o = o; p.ds = ds; p.dn = dn; p.dxm = dxm; p.lddx = lddx; p.dfm = dfm;
     p.lddf = lddf; p.part = (float*)ws_buf; p.B = B; p.N = N; p.heads = heads; p.M = M; p.clamp = clamp_temperature;
+    p.xcd_map = slice_xcd_map(); p.xcd_map = slice_xcd_map();
     p.nchunk = pa2d_slice_nchunk(B, N, heads);
     p.ppc = ppc_for(N, p.nchunk);
     {
