@@ -258,3 +258,71 @@ def test_small_parameter_gradients_accumulate_in_place(dev):
     bufs = (torch.full_like(dw, 0.5), torch.full_like(dbh, 0.5))
     ops.head_bwd(d1, x, w, into=bufs)
     assert rel_l2(bufs[0] - 0.5, dw) < 1e-5 and rel_l2(bufs[1] - 0.5, dbh) < 1e-5
+
+
+def test_split_engine_adversarial_operands(dev):
+    """VERDICT r1 ruling, condition (ii): the fp32-accurate split engine against the exact-fp32-MFMA engine on
+    adversarial conv operands, both measured against fp64.
+      * per-pixel dynamic range 2^+-40 (neighbouring pixels of wildly different magnitude meet in one 3x3 window),
+      * every value scaled to 2^-90 (far below any activation or gradient this model produces),
+      * exact zeros (whole pixels and whole channels),
+      * +-inf / NaN propagation.
+    Asserted: split error <= 2 x exact error (+ 1e-7: both sit at the fp32 rounding floor), zeros give exactly the
+    bias on both, and the non-finite outputs coincide.  DOCUMENTED LIMIT (not rejected: it would take a reduction
+    pass over every operand to detect): an operand whose magnitude is below 2^-102 loses its `lo`, then its `mid`
+    plane to bf16 underflow, so the split degrades gracefully from 24 to 8 significant bits between 2^-102 and 2^-126
+    — asserted here as 'finite and <= 2^-7 relative at 2^-120'.  LayerNorm outputs are O(1) and gradients of a rel-L2
+    loss O(1e-8..1), so the path never gets near; data that does should use engine "f32"."""
+    from transformerbasednavierstokesolver_amd import ops
+    from oracle import transolver_oracle as orc
+    B, H, W, C = 2, 24, 24, 128
+    N = H * W
+    rng = np.random.default_rng(99)
+    wx, wf = _r(rng, C, C, 3, 3, scale=(9 * C) ** -0.5), _r(rng, C, C, 3, 3, scale=(9 * C) ** -0.5)
+    bx, bf = 0.1 * _r(rng, C), 0.1 * _r(rng, C)
+    g = lambda t: t.to(dev)
+
+    def run(xn, engine):
+        return ops.conv3x3x2_fwd(g(xn), g(wx), g(bx), g(wf), g(bf), H, W, engine=engine)
+
+    def ref(xn):
+        xd = xn.double()
+        return torch.cat([orc.conv3x3(xd, wx.double(), bx.double(), H, W), orc.conv3x3(xd, wf.double(), bf.double(), H, W)], -1)
+
+    base = _r(rng, B, N, C)
+    # (1) dynamic range 2^+-40 per pixel
+    scale = torch.from_numpy(np.exp2(rng.uniform(-40, 40, size=(B, N, 1))).astype(np.float32))
+    for name, xn, zero_bias in (("range 2^+-40", base * scale, False), ("all at 2^-90", base * 2.0 ** -90, True)):
+        r = ref(xn)
+        if zero_bias:                      # judge the products, not the O(0.1) bias that would swamp them
+            r = r - torch.cat([bx, bf]).double()
+        errs = {}
+        for e in ("f32", "split"):
+            out = run(xn, e).double().cpu()
+            if zero_bias:
+                out = out - torch.cat([bx, bf]).double()
+            errs[e] = float((out - r).norm() / r.norm())
+        assert errs["split"] <= 2 * errs["f32"] + 1e-7, (name, errs)
+        assert errs["f32"] < 1e-5, (name, errs)
+    # (2) graceful degradation below 2^-102 (documented, see docstring)
+    xn = base * 2.0 ** -120
+    r = ref(xn) - torch.cat([bx, bf]).double()
+    out = run(xn, "split").double().cpu() - torch.cat([bx, bf]).double()
+    assert torch.isfinite(out).all() and float((out - r).norm() / r.norm()) < 2.0 ** -7
+    # (3) exact zeros: zero pixels (rows) and zero channels -> bias exactly where the whole window is zero
+    xz = base.clone()
+    xz[:, : 5 * W] = 0.0                       # first five image rows of every sample
+    xz[..., 7] = 0.0
+    for e in ("f32", "split"):
+        out = run(xz, e).cpu()
+        interior = out.reshape(B, H, W, 2 * C)[:, :4]                     # windows entirely inside the zero rows
+        assert torch.equal(interior, torch.cat([bx, bf]).expand_as(interior)), e
+    # (4) inf / NaN propagation: the non-finite outputs coincide (= the 3x3 neighbourhoods of the poisoned pixels)
+    xp = base.clone()
+    xp[0, 5 * W + 7, 3] = float("inf")
+    xp[1, 11 * W + 2, 0] = float("nan")
+    xp[1, 20 * W + 20, 9] = -float("inf")
+    masks = {e: torch.isfinite(run(xp, e)).cpu() for e in ("f32", "split")}
+    assert torch.equal(masks["f32"], masks["split"])
+    bad = (~masks["split"]).reshape(B, H, W, 2 * C).any(-1)
+    assert int(bad[0].sum()) == 9 and int(bad[1].sum()) == 18            # exactly the three 3x3 windows
