@@ -282,32 +282,32 @@ def test_split_engine_adversarial_operands(dev):
     bx, bf = 0.1 * _r(rng, C), 0.1 * _r(rng, C)
     g = lambda t: t.to(dev)
 
-    def run(xn, engine):
-        return ops.conv3x3x2_fwd(g(xn), g(wx), g(bx), g(wf), g(bf), H, W, engine=engine)
+    zb = torch.zeros(C)
 
-    def ref(xn):
+    def run(xn, engine, bias=True):
+        b1, b2 = (bx, bf) if bias else (zb, zb)
+        return ops.conv3x3x2_fwd(g(xn), g(wx), g(b1), g(wf), g(b2), H, W, engine=engine)
+
+    def ref(xn, bias=True):
         xd = xn.double()
-        return torch.cat([orc.conv3x3(xd, wx.double(), bx.double(), H, W), orc.conv3x3(xd, wf.double(), bf.double(), H, W)], -1)
+        b1, b2 = (bx, bf) if bias else (zb, zb)
+        return torch.cat([orc.conv3x3(xd, wx.double(), b1.double(), H, W), orc.conv3x3(xd, wf.double(), b2.double(), H, W)], -1)
 
     base = _r(rng, B, N, C)
     # (1) dynamic range 2^+-40 per pixel
     scale = torch.from_numpy(np.exp2(rng.uniform(-40, 40, size=(B, N, 1))).astype(np.float32))
-    for name, xn, zero_bias in (("range 2^+-40", base * scale, False), ("all at 2^-90", base * 2.0 ** -90, True)):
-        r = ref(xn)
-        if zero_bias:                      # judge the products, not the O(0.1) bias that would swamp them
-            r = r - torch.cat([bx, bf]).double()
+    for name, xn, with_bias in (("range 2^+-40", base * scale, True), ("all at 2^-90", base * 2.0 ** -90, False)):
+        r = ref(xn, with_bias)              # (tiny operands: zero bias, or the O(0.1) bias would swamp the products)
         errs = {}
         for e in ("f32", "split"):
-            out = run(xn, e).double().cpu()
-            if zero_bias:
-                out = out - torch.cat([bx, bf]).double()
-            errs[e] = float((out - r).norm() / r.norm())
+            out = run(xn, e, with_bias).double().cpu()
+            errs[e] = float(((out - r) * 2.0 ** 80).norm() / (r * 2.0 ** 80).norm())
         assert errs["split"] <= 2 * errs["f32"] + 1e-7, (name, errs)
         assert errs["f32"] < 1e-5, (name, errs)
     # (2) graceful degradation below 2^-102 (documented, see docstring)
     xn = base * 2.0 ** -120
-    r = ref(xn) - torch.cat([bx, bf]).double()
-    out = run(xn, "split").double().cpu() - torch.cat([bx, bf]).double()
+    r = ref(xn, False) * 2.0 ** 110
+    out = run(xn, "split", False).double().cpu() * 2.0 ** 110
     assert torch.isfinite(out).all() and float((out - r).norm() / r.norm()) < 2.0 ** -7
     # (3) exact zeros: zero pixels (rows) and zero channels -> bias exactly where the whole window is zero
     xz = base.clone()

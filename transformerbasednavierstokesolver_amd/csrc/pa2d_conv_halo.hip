@@ -27,16 +27,21 @@ constexpr int TH = 8, TW = 32, BM = TH * TW, BN = 128;
 constexpr int HH = TH + 2, HWD = TW + 2, HROWS = HH * HWD;          // 10 x 34 = 340 halo pixels
 }
 
-template <int NT, typename TO = float>
+// TPB = taps per weight stage (= per barrier): 1 for NT = 3 (96 MFMAs per consumer wave and barrier; LDS is full), 3 for
+// NT = 1 (one tap would be 16 MFMAs per barrier: the kernel would spend its time in s_barrier)
+template <int NT, typename TO = float, int TPB = (NT == 1 ? 3 : 1)>
 __global__ __launch_bounds__(512, 1) void conv_halo_kernel(const KCParams p, const int tiles_x, const int tiles_y,
                                                            const int nimg) {
     constexpr int PITCHB = NT * 64 + 16;
     constexpr int PIECES = NT * 4;                                   // 16-byte pieces per row and chunk
     constexpr int A_BYTES = HROWS * PITCHB;
-    constexpr int B_STAGE = BN * PITCHB;
+    constexpr int B_TAP = BN * PITCHB;                               // weight tile of one tap
+    constexpr int B_STAGE = TPB * B_TAP;
+    constexpr int SPC = 9 / TPB;                                     // weight stages per 32-channel chunk
     constexpr int AP_IT = (HROWS * PIECES + 255) / 256;              // halo pieces per producer thread (16 / 6)
-    constexpr int BP_IT = (BN * PIECES) / 256;                       // weight pieces per producer thread (6 / 2)
+    constexpr int BP_IT = (TPB * BN * PIECES) / 256;                 // weight pieces per producer thread and stage (6)
     constexpr int TM = 4, TN = 2;
+    static_assert(9 % TPB == 0, "taps per stage");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     unsigned char* const a_s = smem;
     unsigned char* const b_s = smem + A_BYTES;
@@ -53,7 +58,8 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(const KCParams p, con
     const int trem = tile_m - img * (tiles_y * tiles_x);
     const int y0 = (trem / tiles_x) * TH, x0 = (trem % tiles_x) * TW;
     const int nch = p.Cin / 32;                                      // 32-channel chunks
-    const int nk = nch * 9;
+    const int nk = nch * 9;                                          // K-steps (chunk, tap) of the weight pack
+    const int nst = nch * SPC;                                       // weight stages = barriers
 
     if (wave >= 4) {
         // ------------------------------------------------------------------ producers
@@ -73,10 +79,11 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(const KCParams p, con
         unsigned bp_off[BP_IT], bp_lds[BP_IT];
 #pragma unroll
         for (int s = 0; s < BP_IT; ++s) {
-            const int q = ptid + 256 * s, row = q / PIECES, piece = q - row * PIECES;
+            const int q = ptid + 256 * s, tapi = q / (BN * PIECES), r = q - tapi * (BN * PIECES);
+            const int row = r / PIECES, piece = r - row * PIECES;
             const int gn = tile_n * BN + row;
-            bp_off[s] = gn < p.N ? ((unsigned)gn * (unsigned)nk * PIECES + piece) * 16u : OOB_OFF;
-            bp_lds[s] = row * PITCHB + piece * 16;
+            bp_off[s] = gn < p.N ? ((unsigned)gn * (unsigned)nk * PIECES + (unsigned)(tapi * PIECES) + piece) * 16u : OOB_OFF;
+            bp_lds[s] = tapi * B_TAP + row * PITCHB + piece * 16;
         }
         u32x4 rq[AP_IT], rp0[BP_IT], rp1[BP_IT];
 #define HA_LOAD(chunk_)                                                                                    \
@@ -90,11 +97,11 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(const KCParams p, con
         _Pragma("unroll") for (int s = 0; s < AP_IT; ++s)                                                  \
             if (ap_lds[s] != 0xFFFFFFFFu) *reinterpret_cast<u32x4*>(a_s + ap_lds[s]) = rq[s];              \
     }
-#define HB_LOAD(kc_, RP)                                                                                   \
+#define HB_LOAD(sg_, RP)      /* stage sg_ = K-steps sg_*TPB .. sg_*TPB + TPB - 1 of the pack */                 \
     {                                                                                                      \
         _Pragma("unroll") for (int s = 0; s < BP_IT; ++s)                                                  \
             RP[s] = __builtin_amdgcn_raw_buffer_load_b128(                                                 \
-                rb_rsrc, bp_off[s] != OOB_OFF ? bp_off[s] + (unsigned)(kc_) * (PIECES * 16u) : OOB_OFF, 0, 0); \
+                rb_rsrc, bp_off[s] != OOB_OFF ? bp_off[s] + (unsigned)((sg_) * TPB) * (PIECES * 16u) : OOB_OFF, 0, 0); \
     }
 #define HB_STORE(stage_, RP)                                                                               \
     {                                                                                                      \
@@ -103,34 +110,34 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(const KCParams p, con
     }
         HA_LOAD(0)
         HB_LOAD(0, rp0)
-        if (nk > 1) HB_LOAD(1, rp1)
+        if (nst > 1) HB_LOAD(1, rp1)
         HA_STORE()
         HB_STORE(0, rp0)
         if (nch > 1) HA_LOAD(1)
-        if (nk > 2) HB_LOAD(2, rp0)
+        if (nst > 2) HB_LOAD(2, rp0)
         __syncthreads();                                  // #0: halo tile of chunk 0 + weight stage 0 are ready
-        for (int kc = 0; kc < nk; kc += 2) {
-            // consumers run K-step kc on weight stage 0
-            if (kc + 1 < nk) {
+        for (int sg = 0; sg < nst; sg += 2) {
+            // consumers run stage sg on weight buffer 0
+            if (sg + 1 < nst) {
                 HB_STORE(1, rp1)
-                if (kc + 3 < nk) HB_LOAD(kc + 3, rp1)
+                if (sg + 3 < nst) HB_LOAD(sg + 3, rp1)
             }
-            __syncthreads();                              // end of K-step kc
-            if (kc % 9 == 8 && kc + 1 < nk) {             // chunk boundary: swap the halo tile between two barriers
+            __syncthreads();                              // end of stage sg
+            if (sg % SPC == SPC - 1 && sg + 1 < nst) {    // chunk boundary: swap the halo tile between two barriers
                 HA_STORE()
-                if (kc / 9 + 2 < nch) HA_LOAD(kc / 9 + 2)
+                if (sg / SPC + 2 < nch) HA_LOAD(sg / SPC + 2)
                 __syncthreads();
             }
-            if (kc + 1 < nk) {
-                // consumers run K-step kc+1 on weight stage 1
-                if (kc + 2 < nk) {
+            if (sg + 1 < nst) {
+                // consumers run stage sg+1 on weight buffer 1
+                if (sg + 2 < nst) {
                     HB_STORE(0, rp0)
-                    if (kc + 4 < nk) HB_LOAD(kc + 4, rp0)
+                    if (sg + 4 < nst) HB_LOAD(sg + 4, rp0)
                 }
-                __syncthreads();                          // end of K-step kc+1
-                if ((kc + 1) % 9 == 8 && kc + 2 < nk) {
+                __syncthreads();                          // end of stage sg+1
+                if ((sg + 1) % SPC == SPC - 1 && sg + 2 < nst) {
                     HA_STORE()
-                    if ((kc + 1) / 9 + 2 < nch) HA_LOAD((kc + 1) / 9 + 2)
+                    if ((sg + 1) / SPC + 2 < nch) HA_LOAD((sg + 1) / SPC + 2)
                     __syncthreads();
                 }
             }
@@ -157,41 +164,44 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(const KCParams p, con
     const unsigned b_frag = (unsigned)((wn * 64 + (lane & 31)) * PITCHB + (lane >> 5) * 16);
     __syncthreads();                                      // #0
     int tap = 0;
-    for (int kc = 0; kc < nk; ++kc) {
-        const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
-        const unsigned char* af_base = a_s + a_frag + (dy * HWD + dx) * PITCHB;
-        const unsigned char* bf_base = b_s + (kc & 1) * B_STAGE + b_frag;
+    for (int sg = 0; sg < nst; ++sg) {
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 af[TM][NT], bf[TN][NT];
+        for (int tt = 0; tt < TPB; ++tt, ++tap) {
+            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+            const unsigned char* af_base = a_s + a_frag + (dy * HWD + dx) * PITCHB;
+            const unsigned char* bf_base = b_s + (sg & 1) * B_STAGE + tt * B_TAP + b_frag;
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int ks = 0; ks < 2; ++ks) {
+                bf16x8 af[TM][NT], bf[TN][NT];
 #pragma unroll
-                for (int q = 0; q < NT; ++q)
-                    af[i][q] = *reinterpret_cast<const bf16x8*>(af_base + i * (HWD * PITCHB) + q * 64 + ks * 32);
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
+                    for (int q = 0; q < NT; ++q)
+                        af[i][q] = *reinterpret_cast<const bf16x8*>(af_base + i * (HWD * PITCHB) + q * 64 + ks * 32);
 #pragma unroll
-                for (int q = 0; q < NT; ++q)
-                    bf[j][q] = *reinterpret_cast<const bf16x8*>(bf_base + j * 32 * PITCHB + q * 64 + ks * 32);
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                    for (int q = 0; q < NT; ++q)
+                        bf[j][q] = *reinterpret_cast<const bf16x8*>(bf_base + j * 32 * PITCHB + q * 64 + ks * 32);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    if constexpr (NT == 3) {   // smallest terms first
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) {
+                        if constexpr (NT == 3) {   // smallest terms first
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
+                        }
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
                     }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
-                }
+            }
         }
-        __syncthreads();                                  // end of K-step kc
-        if (++tap == 9) {
+        __syncthreads();                                  // end of stage sg
+        if (tap == 9) {
             tap = 0;
-            if (kc + 1 < nk) __syncthreads();             // the producers swapped the halo tile in between
+            if (sg + 1 < nst) __syncthreads();            // the producers swapped the halo tile in between
         }
     }
 
@@ -240,7 +250,7 @@ int launch_conv_halo(const KCParams& p, hipStream_t st) {
     const int tiles_m = nimg * tiles_y * tiles_x, tiles_n = ceil_div(p.N, BN);
     const dim3 grid(ceil_div(tiles_m, 8) * 8 * tiles_n);
     const int pitch = NT * 64 + 16;
-    const int smem = HROWS * pitch + 2 * BN * pitch;
+    const int smem = HROWS * pitch + 2 * (NT == 1 ? 3 : 1) * BN * pitch;
     static bool attr3 = false, attr1 = false;
     if (NT == 3) {
         if (!attr3) {

@@ -242,64 +242,46 @@ __global__ __launch_bounds__(512, 1) void gemm_mc_planes_big_kernel(const MCPlan
     const __amdgpu_buffer_rsrc_t ra_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.PA), 0, p.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rb_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.PB), 0, p.b_bytes, 0x00020000);
 
-    // staging assignment: piece q = tid + 512*s: operand, row (16*KS), 32-column group c (8), plane, 16-byte piece (4)
-    int s_row[NP], s_dy[NP], s_dx[NP], s_shift[NP];
-    unsigned s_goff[NP], s_lds[NP];
-    bool s_isb[NP];
-#pragma unroll
-    for (int s = 0; s < NP; ++s) {
-        const int q = tid + 512 * s;
-        const int per_op = 16 * KS * 32 * NT;
-        const int op = q / per_op, r = q - op * per_op;
-        const int row = r / (32 * NT), rr = r - row * (32 * NT);
-        const int c = rr / (4 * NT), pp = rr - c * (4 * NT);
-        const int plane = pp >> 2, piece = pp & 3;
-        s_row[s] = row;
-        s_isb[s] = op != 0;
-        int chunk;
-        bool colok;
-        if (op) {          // X: column group c of this tile = columns jc..jc+31 = one tap, one 32-channel chunk
-            const int jc = tj * 256 + c * 32;
-            const int tap = p.taps == 1 ? 4 : jc / p.Cin;              // plain GEMM: the centre tap (no shift)
-            chunk = p.taps == 1 ? (jc >> 5) : ((jc - tap * p.Cin) >> 5);
-            colok = jc < p.Nj;
-            s_dy[s] = tap / 3 - 1;
-            s_dx[s] = tap - (tap / 3) * 3 - 1;
-            s_shift[s] = s_dy[s] * p.W + s_dx[s];
-        } else {           // dOut: channels ti*256 + c*32 ..
-            chunk = ((ti * 256) >> 5) + c;
-            colok = ti * 256 + c * 32 < p.Mi;
-            s_dy[s] = s_dx[s] = s_shift[s] = 0;
-        }
-        s_goff[s] = colok ? (unsigned)((chunk * NT + plane) * 64 + piece * 16) : OOB_OFF;
-        const int ch16 = c * 4 + piece;              // 16-byte chunk index inside the 512-byte image row
-        s_lds[s] = (unsigned)(((op * NT + plane) * KS + (row >> 4)) * PIMG) + 512u * (row & 15) +
-                   16u * (ch16 ^ ((((row & 15) & 3) << 2) | (((row & 15) >> 2) & 3)));
-    }
-    u32x4 rg[NP];
-#define MB_LOAD(c_)                                                                                       \
+    // staging assignment: the 512 threads cover ONE plane image of ONE 16-row K-step (16 rows x 32 pieces of 16 bytes);
+    // piece s of a thread = (operand, plane, k-step) of the same (row, column group c, piece) -> the metadata is per
+    // thread, not per piece (a second register set for a 2-stage-deep prefetch was tried: 256 VGPRs + 160 spilled)
+    const int row16 = tid >> 5, cgrp = (tid & 31) >> 2, piece = tid & 3;
+    const bool colok_a = ti * 256 + cgrp * 32 < p.Mi;
+    const unsigned goff_a = (unsigned)((((ti * 256) >> 5) + cgrp) * NT * 64 + piece * 16);
+    const int jc = tj * 256 + cgrp * 32;             // X: column group = one tap, one 32-channel chunk
+    const int tap = p.taps == 1 ? 4 : jc / p.Cin;    // plain GEMM: the centre tap (no shift)
+    const bool colok_b = jc < p.Nj;
+    const unsigned goff_b = (unsigned)((p.taps == 1 ? (jc >> 5) : ((jc - tap * p.Cin) >> 5)) * NT * 64 + piece * 16);
+    const int tap_dy = tap / 3 - 1, tap_dx = tap - (tap / 3) * 3 - 1, tap_shift = tap_dy * p.W + tap_dx;
+    const unsigned pitch_a = (unsigned)(p.chA * NT * 64), pitch_b = (unsigned)(p.chB * NT * 64);
+    const unsigned lds_off = 512u * row16 + 16u * ((unsigned)(cgrp * 4 + piece) ^ (unsigned)(((row16 & 3) << 2) | ((row16 >> 2) & 3)));
+#define MB_LOAD(c_, RG)                                                                                   \
     {                                                                                                     \
-        const int m0_ = (c_) * 16;                                                                        \
-        _Pragma("unroll") for (int s = 0; s < NP; ++s) {                                                  \
-            const int m_ = m0_ + s_row[s];                                                                \
-            bool ok_ = s_goff[s] != OOB_OFF && m_ < p.Mk && (KS == 1 || (c_) + (s_row[s] >> 4) < c_end);  \
+        _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                               \
+            const int m_ = ((c_) + ks) * 16 + row16;                                                      \
+            const bool okr_ = m_ < p.Mk && (c_) + ks < c_end;      /* next split's rows stay out */       \
+            bool okb_ = okr_ && colok_b;                                                                  \
             int mm_ = m_;                                                                                 \
-            if (s_isb[s] && p.taps != 1) {                                                                \
+            if (p.taps != 1) {                                                                            \
                 const int n_ = m_ % HW;                                                                   \
                 const int y_ = n_ / p.W, x_ = n_ - y_ * p.W;                                              \
-                ok_ = ok_ && (unsigned)(y_ + s_dy[s]) < (unsigned)p.H && (unsigned)(x_ + s_dx[s]) < (unsigned)p.W; \
-                mm_ = m_ + s_shift[s];                                                                    \
+                okb_ = okb_ && (unsigned)(y_ + tap_dy) < (unsigned)p.H && (unsigned)(x_ + tap_dx) < (unsigned)p.W; \
+                mm_ = m_ + tap_shift;                                                                     \
             }                                                                                             \
-            const unsigned rowb_ = (unsigned)mm_ * (unsigned)((s_isb[s] ? p.chB : p.chA) * NT * 64);      \
-            rg[s] = s_isb[s] ? __builtin_amdgcn_raw_buffer_load_b128(rb_rsrc, ok_ ? rowb_ + s_goff[s] : OOB_OFF, 0, 0) \
-                             : __builtin_amdgcn_raw_buffer_load_b128(ra_rsrc, ok_ ? rowb_ + s_goff[s] : OOB_OFF, 0, 0); \
+            const unsigned oa_ = (okr_ && colok_a) ? (unsigned)m_ * pitch_a + goff_a : OOB_OFF;           \
+            const unsigned ob_ = okb_ ? (unsigned)mm_ * pitch_b + goff_b : OOB_OFF;                       \
+            _Pragma("unroll") for (int pl = 0; pl < NT; ++pl) {                                           \
+                RG[pl * KS + ks] = __builtin_amdgcn_raw_buffer_load_b128(ra_rsrc, oa_ == OOB_OFF ? OOB_OFF : oa_ + pl * 64u, 0, 0); \
+                RG[(NT + pl) * KS + ks] = __builtin_amdgcn_raw_buffer_load_b128(rb_rsrc, ob_ == OOB_OFF ? OOB_OFF : ob_ + pl * 64u, 0, 0); \
+            }                                                                                             \
         }                                                                                                 \
     }
-#define MB_STORE(buf_)                                                                                    \
+#define MB_STORE(buf_, RG)                                                                                \
     {                                                                                                     \
         _Pragma("unroll") for (int s = 0; s < NP; ++s)                                                    \
-            *reinterpret_cast<u32x4*>(smem + (buf_) * STAGE + s_lds[s]) = rg[s];                          \
+            *reinterpret_cast<u32x4*>(smem + (buf_) * STAGE + s * PIMG + lds_off) = RG[s];                \
     }
+    u32x4 rg0[NP];
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -329,51 +311,54 @@ __global__ __launch_bounds__(512, 1) void gemm_mc_planes_big_kernel(const MCPlan
         }
     }
 
+#define MB_COMPUTE(buf_)                                                                                  \
+    _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                                   \
+        const unsigned char* st = smem + (buf_) * STAGE + ks * PIMG;                                      \
+        bf16x8 af[4][NT], bf[2][NT];                                                                      \
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;                                        \
+        _Pragma("unroll") for (int pl = 0; pl < NT; ++pl) {                                               \
+            _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                               \
+                const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + pl * KS * PIMG + fa[t][0])); \
+                const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + pl * KS * PIMG + fa[t][1])); \
+                af[t][pl] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7)); \
+            }                                                                                             \
+            _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                               \
+                const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + (NT + pl) * KS * PIMG + fb[t][0])); \
+                const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + (NT + pl) * KS * PIMG + fb[t][1])); \
+                bf[t][pl] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7)); \
+            }                                                                                             \
+        }                                                                                                 \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i)                                                     \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                               \
+                if constexpr (NT == 3) {   /* smallest terms first */                                     \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0); \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0); \
+                }                                                                                         \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0); \
+            }                                                                                             \
+    }
+    // write-after-barrier order: at the top of stage c the registers (loaded during stage c-KS) are stored into the
+    // buffer that stage c-KS just released, the loads of stage c+2KS are issued at once, then the MFMAs of stage c run
+    // -> LDS always holds the current AND the next stage, the registers the one after, with ONE register set
     if (c_begin < c_end) {
-        MB_LOAD(c_begin)
-        MB_STORE(0)
+        MB_LOAD(c_begin, rg0)
+        MB_STORE(0, rg0)
+        if (c_begin + KS < c_end) MB_LOAD(c_begin + KS, rg0)
     }
     __syncthreads();
     for (int c = c_begin; c < c_end; c += KS) {
         const int buf = ((c - c_begin) / KS) & 1;
-        if (c + KS < c_end) MB_LOAD(c + KS)
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const unsigned char* st = smem + buf * STAGE + ks * PIMG;
-            bf16x8 af[4][NT], bf[2][NT];
-            typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-#pragma unroll
-            for (int pl = 0; pl < NT; ++pl) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    const s16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + pl * KS * PIMG + fa[t][0]));
-                    const s16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + pl * KS * PIMG + fa[t][1]));
-                    af[t][pl] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7));
-                }
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    const s16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + (NT + pl) * KS * PIMG + fb[t][0]));
-                    const s16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(st + (NT + pl) * KS * PIMG + fb[t][1]));
-                    bf[t][pl] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7));
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if constexpr (NT == 3) {   // smallest terms first
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][1], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bf[j][0], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][2], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bf[j][0], acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][1], acc[i][j], 0, 0, 0);
-                    }
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
-                }
+        if (c + KS < c_end) {
+            MB_STORE(buf ^ 1, rg0)
+            if (c + 2 * KS < c_end) MB_LOAD(c + 2 * KS, rg0)
         }
-        if (c + KS < c_end) MB_STORE(buf ^ 1)
+        MB_COMPUTE(buf)
         __syncthreads();
     }
+#undef MB_COMPUTE
 #undef MB_LOAD
 #undef MB_STORE
 
@@ -451,14 +436,14 @@ int launch_mc_planes_big_raw(const void* PA, int Mi, const void* PB, int Cin, in
         }
         hipLaunchKernelGGL((gemm_mc_planes_big_kernel<3, 1>), grid, dim3(512), smem, st, p, per_xcd);
     } else {
-        const int smem = 2 * 2 * 1 * 2 * 8192;
+        const int smem = 2 * 2 * 1 * 4 * 8192;      // NT = 1: four 16-row K-steps per stage (64 MFMAs per wave and barrier)
         if (!attr1) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mc_planes_big_kernel<1, 2>),
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mc_planes_big_kernel<1, 4>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, smem);
             if (e != hipSuccess) return (int)e;
             attr1 = true;
         }
-        hipLaunchKernelGGL((gemm_mc_planes_big_kernel<1, 2>), grid, dim3(512), smem, st, p, per_xcd);
+        hipLaunchKernelGGL((gemm_mc_planes_big_kernel<1, 4>), grid, dim3(512), smem, st, p, per_xcd);
     }
     PA2D_CHECK_LAUNCH();
     return PA2D_OK;
