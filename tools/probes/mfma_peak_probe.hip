@@ -7,7 +7,7 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-template <int LDS_READS>   // 0: operands stay in registers; 1: 18 ds_read_b128 per 48 MFMAs
+template <int LDS_READS, int TERM_MAJOR = 0>   // LDS_READS 0: operands stay in registers; 1: 18 ds_read_b128 per 48 MFMAs
 __global__ __launch_bounds__(512, 1) void probe(float* out, int iters, int active_waves) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -31,6 +31,16 @@ __global__ __launch_bounds__(512, 1) void probe(float* out, int iters, int activ
 #pragma unroll
                 for (int q = 0; q < 3; ++q) b[j][q] = *reinterpret_cast<const bf16x8*>(smem + 70720 + base + j * 6656 + q * 64 + (it & 1) * 32);
         }
+        if (TERM_MAJOR) {       // consecutive MFMAs write different accumulators
+            constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][TA[t]], b[j][TB[t]], acc[i * 2 + j], 0, 0, 0);
+        } else
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -49,14 +59,14 @@ __global__ __launch_bounds__(512, 1) void probe(float* out, int iters, int activ
     out[blockIdx.x * 512 + threadIdx.x] = s;
 }
 
-template <int L> static void run(const char* name, int active, int iters, float* out) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&probe<L>), hipFuncAttributeMaxDynamicSharedMemorySize, 124 * 1024);
+template <int L, int TM = 0> static void run(const char* name, int active, int iters, float* out) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&probe<L, TM>), hipFuncAttributeMaxDynamicSharedMemorySize, 124 * 1024);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const int grid = 256 * 8;
-    hipLaunchKernelGGL((probe<L>), dim3(grid), dim3(512), 124 * 1024, 0, out, 64, active);
+    hipLaunchKernelGGL((probe<L, TM>), dim3(grid), dim3(512), 124 * 1024, 0, out, 64, active);
     hipDeviceSynchronize();
     hipEventRecord(e0);
-    hipLaunchKernelGGL((probe<L>), dim3(grid), dim3(512), 124 * 1024, 0, out, iters, active);
+    hipLaunchKernelGGL((probe<L, TM>), dim3(grid), dim3(512), 124 * 1024, 0, out, iters, active);
     hipEventRecord(e1); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double flops = (double)grid * active * iters * 48.0 * 32768.0;
@@ -69,5 +79,7 @@ int main() {
     run<0>("8 waves/CU (2/SIMD), registers only", 8, 2000, out);
     run<1>("4 waves/CU (1/SIMD), 18 ds_read_b128 / 48 MFMA", 4, 4000, out);
     run<1>("8 waves/CU (2/SIMD), 18 ds_read_b128 / 48 MFMA", 8, 2000, out);
+    run<0, 1>("4 waves/CU, registers only, term-major order", 4, 4000, out);
+    run<1, 1>("4 waves/CU, 18 ds_read_b128 / 48 MFMA, term-major", 4, 4000, out);
     return 0;
 }
