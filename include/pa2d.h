@@ -179,6 +179,31 @@ int pa2d_rel_l2_fwd(const float* pred, const float* y, float* dnorm, float* ynor
 int pa2d_rel_l2_bwd(const float* pred, const float* y, const float* dnorm, const float* ynorm,
                     const float* gout, float* dpred, int B, long long L, pa2d_stream_t stream);
 
+/* ==== operand-planes interface of the bf16 engines (fp32 storage; PA2D_ENGINE_SPLIT: 3 planes, PA2D_ENGINE_BF16: 1).
+ * The conv GEMMs of these engines stage their activation operand as a bf16 plane image [row][C/32][NT][32].  By default
+ * pa2d_conv3x3x2_fwd/bwd make it from the fp32 tensor in a pre-pass; with the entry points below the PRODUCER of the
+ * operand writes the image and nothing else: LayerNorm forward (…_2D.py:70 feeding Physics_Attention.py:94,96) and the
+ * slice backward (autograd of Physics_Attention.py:98-101 feeding the autograd of :94,96), which also yields the conv
+ * bias gradients.  Use when pa2d_conv3x3x2_planes_mask(...) == 7. */
+size_t pa2d_planes_bytes(long long rows, int C, int engine);
+int pa2d_conv3x3x2_planes_mask(int B, int H, int W, int C, int engine);
+int pa2d_layernorm_fwd_planes(const float* x, const float* gamma, const float* beta, void* planes, float* mean,
+                              float* rstd, int rows, int C, float eps, int engine, pa2d_stream_t stream);
+int pa2d_conv3x3x2_fwd_planes(const void* xn_planes, const float* wx, const float* bx, const float* wf, const float* bf,
+                              float* out, const void* prepacked, void* ws, size_t ws_bytes, int B, int H, int W, int C,
+                              int engine, pa2d_stream_t stream, void* ev_start, void* ev_stop);
+size_t pa2d_conv3x3x2_workspace_planes(int B, int H, int W, int C, int engine);
+int pa2d_conv3x3x2_bwd_planes(const void* dout_planes, const void* xn_planes, const float* wx, const float* wf, float* dxn,
+                              float* dwx, float* dwf, const void* prepacked, void* ws, size_t ws_bytes, int B, int H,
+                              int W, int C, int accumulate, int engine, pa2d_stream_t stream, void* ev_start,
+                              void* ev_stop);
+int pa2d_slice_bwd_points_planes(const float* xm, long long ldx, const float* fm, long long ldf, const float* dy,
+                                 long long lddy, const float* ws, const float* bs, const float* temperature,
+                                 const float* o, const float* ds, const float* dn, void* dxf_planes, float* dbx,
+                                 float* dbf, float* dws, float* dbs, float* dtemperature, void* ws_buf,
+                                 size_t ws_bytes, int B, int N, int heads, int D, int M, int clamp_temperature,
+                                 int accumulate, int engine, pa2d_stream_t stream, void* ev_start, void* ev_stop);
+
 /* ==== bf16-STORAGE variants (BASELINE configs[2] "NS 64x64 bf16 ... DDP" and configs[4] "Darcy ... bf16"; the reference
  * would reach these numerics with torch.autocast(bfloat16) around model/Transolver_Structured_Mesh_2D.py:202-220).
  * Same stages, same argument order as the fp32 entry points above, but every ACTIVATION pointer (inputs, outputs,

@@ -326,3 +326,58 @@ def test_split_engine_adversarial_operands(dev):
     assert torch.equal(masks["f32"], masks["split"])
     bad = (~masks["split"]).reshape(B, H, W, 2 * C).any(-1)
     assert int(bad[0].sum()) == 9 and int(bad[1].sum()) == 18            # exactly the three 3x3 windows
+
+
+def _unplane(planes, rows, C, nt):
+    """fp64 tensor [rows, C] held by a plane image [row][C/32][nt][32] bf16 (sum of the planes)"""
+    p = planes.view(torch.bfloat16).view(rows, C // 32, nt, 32).double().sum(2)
+    return p.reshape(rows, C)
+
+
+@pytest.mark.parametrize("engine,nt", [("split", 3), ("bf16", 1)])
+def test_operand_planes_interface(dev, engine, nt):
+    """The producers of the conv operands emit the bf16 plane image directly (LayerNorm forward, slice backward + conv bias
+    gradients) and the conv forward / backward consume it: same results as the fp32-tensor + pre-pass route."""
+    from transformerbasednavierstokesolver_amd import ops
+    B, H, W, heads, D, M = 2, 64, 64, 8, 32, 64
+    C, N = heads * D, H * W
+    assert ops.conv_planes_mask(B, H, W, C, engine) == 7 and ops.conv_planes_mask(B, H, W, 32, engine) != 7
+    rng = np.random.default_rng(17)
+    g = lambda t: t.to(dev).contiguous()
+    tol = 1e-6 if nt == 3 else 4e-3
+    # LayerNorm -> planes
+    x, gam, bet = g(_r(rng, B * N, C) * 2 + 0.3), g(1 + 0.1 * _r(rng, C)), g(0.1 * _r(rng, C))
+    y, mean, rstd = ops.layernorm_fwd(x, gam, bet)
+    yp, mean2, rstd2 = ops.layernorm_fwd_planes(x, gam, bet, engine)
+    assert torch.equal(mean, mean2) and torch.equal(rstd, rstd2)
+    assert rel_l2(_unplane(yp, B * N, C, nt), y) < tol
+    # conv forward from planes == conv forward from the fp32 tensor (bit-identical for the 3-plane split: same planes)
+    wx, wf = g(_r(rng, C, C, 3, 3, scale=(9 * C) ** -0.5)), g(_r(rng, C, C, 3, 3, scale=(9 * C) ** -0.5))
+    bx, bf = g(0.1 * _r(rng, C)), g(0.1 * _r(rng, C))
+    out_ref = ops.conv3x3x2_fwd(y.view(B, N, C), wx, bx, wf, bf, H, W, engine=engine)
+    out_pl = ops.conv3x3x2_fwd_planes(yp, wx, bx, wf, bf, B, H, W, engine)
+    assert torch.equal(out_pl, out_ref)
+    # slice backward -> planes + conv bias gradients
+    xf32, ws, bs, temp, wq, wk, wv, dy32 = _slice_inputs(B, N, heads, D, M, 5)
+    xf, dy = g(xf32), g(dy32)
+    spart, npart = ops.slice_scatter(xf, 2 * C, 0, xf, 2 * C, C, g(ws), g(bs), g(temp), B, N, heads, D, M)
+    s_, nrm, o = ops.token_attn_fwd(spart, npart, g(wq), g(wk), g(wv))
+    dopart, _ = ops.slice_scatter(xf, 2 * C, 0, dy, C, 0, g(ws), g(bs), g(temp), B, N, heads, D, M, want_norm=False)
+    ds, dn, *_ = ops.token_attn_bwd(s_, nrm, g(wq), g(wk), g(wv), dopart)
+    dxf, dws, dbs, dtemp = ops.slice_bwd_points(xf, dy, g(ws), g(bs), g(temp), o, ds, dn, B, N, heads, D, M)
+    dxfp, dbx, dbf, dws2, dbs2, dtemp2 = ops.slice_bwd_points_planes(xf, dy, g(ws), g(bs), g(temp), o, ds, dn, B, N, heads,
+                                                                     D, M, engine)
+    assert rel_l2(_unplane(dxfp, B * N, 2 * C, nt), dxf.view(B * N, 2 * C)) < tol
+    assert torch.equal(dws, dws2) and torch.equal(dbs, dbs2) and torch.equal(dtemp, dtemp2)
+    colsum = dxf.view(B * N, 2 * C).double().sum(0)
+    assert rel_l2(dbx, colsum[:C]) < 1e-5 and rel_l2(dbf, colsum[C:]) < 1e-5
+    # conv backward from the two plane images == conv backward from fp32 tensors
+    dxn_ref, dwx_ref, dbx_ref, dwf_ref, dbf_ref = ops.conv3x3x2_bwd(dxf, y.view(B, N, C), wx, wf, H, W, engine=engine)
+    dxn, dwx, dwf = ops.conv3x3x2_bwd_planes(dxfp, yp, wx, wf, B, H, W, engine)
+    assert rel_l2(dxn, dxn_ref) < 1e-6 and rel_l2(dwx, dwx_ref) < 1e-6 and rel_l2(dwf, dwf_ref) < 1e-6
+    assert rel_l2(dbx, dbx_ref) < 1e-5 and rel_l2(dbf, dbf_ref) < 1e-5
+    # accumulate flag
+    into = tuple(torch.full_like(t, 0.25) for t in (dbx, dbf, dws, dbs, dtemp))
+    ops.slice_bwd_points_planes(xf, dy, g(ws), g(bs), g(temp), o, ds, dn, B, N, heads, D, M, engine, into=into)
+    for got, ref in zip(into, (dbx, dbf, dws, dbs, dtemp)):
+        assert rel_l2(got - 0.25, ref) < 1e-5

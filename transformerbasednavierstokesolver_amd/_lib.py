@@ -63,6 +63,14 @@ for _name in ("pa2d_layernorm_fwd", "pa2d_layernorm_bwd", "pa2d_slice_scatter", 
               "pa2d_head_fwd", "pa2d_head_bwd"):
     SIGNATURES[_name + "_bf16"] = SIGNATURES[_name]
 SIGNATURES.update({
+    "pa2d_planes_bytes": (_sz, [_ll, _i, _i]),
+    "pa2d_conv3x3x2_planes_mask": (_i, [_i, _i, _i, _i, _i]),
+    "pa2d_layernorm_fwd_planes": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, C.c_float, _i, _st]),
+    "pa2d_conv3x3x2_fwd_planes": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _i, _i, _st, _st, _st]),
+    "pa2d_conv3x3x2_workspace_planes": (_sz, [_i, _i, _i, _i, _i]),
+    "pa2d_conv3x3x2_bwd_planes": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _i, _i, _i, _st, _st, _st]),
+    "pa2d_slice_bwd_points_planes": (_i, [_f, _ll, _f, _ll, _f, _ll, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f,
+                                          _sz, _i, _i, _i, _i, _i, _i, _i, _i, _st, _st, _st]),
     "pa2d_gemm_bias_act_fwd_bf16": (_i, [_f, _ll, _f, _ll, _f, _f, _ll, _f, _ll, _f, _ll, _i, _i, _i, _i, _st]),
     "pa2d_gemm_bwd_data_bf16": (_i, [_f, _ll, _f, _ll, _f, _ll, _i, _f, _ll, _f, _i, _i, _i, _st]),
     "pa2d_gemm_bwd_weight_workspace_bf16": (_sz, [_i, _i, _i]),

@@ -326,6 +326,93 @@ int pa2d_conv3x3x2_bwd(const float* dout, const float* xn, const float* wx, cons
 
 
 // =============================================================================================
+// Operand-planes interface of the bf16 engines (fp32 storage): the producers of the conv operands (LayerNorm forward,
+// slice backward) can emit the bf16 plane image directly (pa2d_layernorm_fwd_planes, pa2d_slice_bwd_points_planes); these
+// entry points consume it, so no fp32 copy of the operand and no split pre-pass exists.
+
+// bytes of the plane image of a [rows, C] tensor under `engine` (0 for PA2D_ENGINE_F32)
+size_t pa2d_planes_bytes(long long rows, int C, int engine) {
+    if (engine != 1 && engine != 2) return 0;
+    return planes_bytes(rows, C, engine == 2 ? 1 : 3);
+}
+
+// which conv operands `engine` consumes as planes at this shape: bit 0 = X in the forward GEMM, bit 1 = X in the weight
+// gradient, bit 2 = dOut in the data AND weight gradient.  The *_planes entry points need all three (mask == 7).
+int pa2d_conv3x3x2_planes_mask(int B, int H, int W, int C, int engine) {
+    if (!engine_ok(engine) || B <= 0) return 0;
+    const int M = B * H * W;
+    int m = 0;
+    if (conv_planes_bytes(engine, M, 2 * C, C)) m |= 1;
+    if (conv_dw_kind(engine, M, C)) m |= 2;
+    if (conv_planes_bytes(engine, M, C, 2 * C) && conv_dw_kind(engine, M, C)) m |= 4;
+    return m;
+}
+
+int pa2d_conv3x3x2_fwd_planes(const void* xn_planes, const float* wx, const float* bx, const float* wf, const float* bf,
+                              float* out, const void* prepacked, void* ws, size_t ws_bytes, int B, int H, int W, int C,
+                              int engine, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    if (B <= 0) return PA2D_OK;
+    if ((pa2d_conv3x3x2_planes_mask(B, H, W, C, engine) & 1) == 0) return PA2D_ERR_UNSUPPORTED;
+    if (ws_bytes < pa2d_conv3x3x2_pack_bytes(C)) return PA2D_ERR_WORKSPACE;
+    const float* pack = (const float*)prepacked;
+    if (!pack) {
+        const int rc = conv_pack(wx, wf, (float*)ws, B * H * W, C, 0, engine, st);
+        if (rc) return rc;
+        pack = (const float*)ws;
+    }
+    KCParams p = {};
+    p.engine = engine;
+    p.A = (const float*)xn_planes; p.apre = 1;
+    p.lda = C; p.B = pack; p.ldb = 9 * C; p.C = out; p.ldc = 2 * C;
+    p.bias = bx; p.bias2 = bf; p.bias_split = C;
+    p.M = B * H * W; p.N = 2 * C; p.K = 9 * C; p.H = H; p.W = W; p.Cin = C;
+    return launch_kc(p, true, st, ev_start, ev_stop);
+}
+
+size_t pa2d_conv3x3x2_workspace_planes(int B, int H, int W, int C, int engine) {
+    const MCPlan pl = conv_dw_plan(engine, B * H * W, C);
+    return pa2d_conv3x3x2_pack_bytes(C) + pl.slab_floats * sizeof(float);
+}
+
+// dxn (may be NULL), dwx / dwf ((+)= per accumulate) from the plane images of dOut [B*H*W, 2C] and X [B*H*W, C];
+// the bias gradients come from pa2d_slice_bwd_points_planes
+int pa2d_conv3x3x2_bwd_planes(const void* dout_planes, const void* xn_planes, const float* wx, const float* wf, float* dxn,
+                              float* dwx, float* dwf, const void* prepacked, void* ws, size_t ws_bytes, int B, int H, int W,
+                              int C, int accumulate, int engine, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    if (B <= 0) {
+        if (accumulate) return PA2D_OK;
+        const size_t wb = sizeof(float) * (size_t)C * C * 9;
+        const int rz = pa2d_zero(dwx, wb, st);
+        return rz ? rz : pa2d_zero(dwf, wb, st);
+    }
+    if (pa2d_conv3x3x2_planes_mask(B, H, W, C, engine) != 7) return PA2D_ERR_UNSUPPORTED;
+    if (ws_bytes < pa2d_conv3x3x2_workspace_planes(B, H, W, C, engine)) return PA2D_ERR_WORKSPACE;
+    float* scratch = (float*)((char*)ws + pa2d_conv3x3x2_pack_bytes(C));
+    const int M = B * H * W, NT = engine == 2 ? 1 : 3;
+    int rc;
+    if (dxn) {
+        const float* pack = (const float*)prepacked;
+        if (!pack) {
+            rc = conv_pack(wx, wf, (float*)ws, M, C, 1, engine, st);
+            if (rc) return rc;
+            pack = (const float*)ws;
+        }
+        KCParams p = {};
+        p.engine = engine;
+        p.A = (const float*)dout_planes; p.apre = 1;
+        p.lda = 2 * C; p.B = pack; p.ldb = 9 * 2 * C; p.C = dxn; p.ldc = C;
+        p.M = M; p.N = C; p.K = 9 * 2 * C; p.H = H; p.W = W; p.Cin = 2 * C;
+        rc = launch_kc(p, true, st, ev_start, ev_stop);
+        if (rc) return rc;
+    }
+    const MCPlan pl = conv_dw_plan(engine, M, C);
+    rc = pl.big == 2 ? launch_mc_planes_big(dout_planes, xn_planes, C, C, M, H, W, scratch, pl, NT, st)
+                     : launch_mc_planes(dout_planes, xn_planes, C, C, M, H, W, scratch, pl, NT, st);
+    if (rc) return rc;
+    return launch_reduce(scratch, pl.splits, (long long)2 * C * 9 * C, dwx, dwf, 1, C, C, st, accumulate);
+}
+
+// =============================================================================================
 // bf16-STORAGE variants (BASELINE configs[2] / [4] as stated): activations, saved tensors and inter-kernel gradients are
 // bf16 in HBM; weights, biases and every parameter gradient stay fp32; all products are ONE bf16 MFMA term with fp32
 // accumulation (the arithmetic of PA2D_ENGINE_BF16, minus its fp32 round trips: a bf16 tensor IS the 1-plane operand

@@ -55,6 +55,68 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict_
     }
 }
 
+// LayerNorm whose output leaves ONLY as the bf16 plane image [row][C/32][NT][32] that the conv GEMMs of the bf16 engines
+// stage (NT = 3: exact hi+mid+lo split, NT = 1: rounded): no fp32 y, no split pre-pass in front of the conv
+template <int NT>
+__global__ __launch_bounds__(256) void layernorm_fwd_planes_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                                   const float* __restrict__ b,
+                                                                   unsigned short* __restrict__ planes,
+                                                                   float* __restrict__ mean, float* __restrict__ rstd,
+                                                                   int rows, int C, float eps) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nvec = C >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    const float4* b4 = reinterpret_cast<const float4*>(b);
+    for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+        const float* xrow = x + (size_t)row * C;
+        float4 v[LN_MAXV];
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < LN_MAXV; ++k) {
+            const int i = lane + 64 * k;
+            v[k] = i < nvec ? *reinterpret_cast<const float4*>(xrow + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f);
+            s += v[k].x + v[k].y + v[k].z + v[k].w;
+        }
+        const float mu = wave_sum(s) / C;
+        float q = 0.f;
+#pragma unroll
+        for (int k = 0; k < LN_MAXV; ++k) {
+            if (lane + 64 * k < nvec) {
+                const float a = v[k].x - mu, bb = v[k].y - mu, c = v[k].z - mu, d = v[k].w - mu;
+                q += a * a + bb * bb + c * c + d * d;
+            }
+        }
+        const float rs = 1.0f / sqrtf(wave_sum(q) / C + eps);
+        unsigned short* prow = planes + (size_t)row * C * NT;
+#pragma unroll
+        for (int k = 0; k < LN_MAXV; ++k) {
+            const int i = lane + 64 * k;
+            if (i < nvec) {
+                const float4 gg = g4[i], bb = b4[i];
+                float r[4] = {(v[k].x - mu) * rs * gg.x + bb.x, (v[k].y - mu) * rs * gg.y + bb.y,
+                              (v[k].z - mu) * rs * gg.z + bb.z, (v[k].w - mu) * rs * gg.w + bb.w};
+                const int c0 = 4 * i;                               // channels c0 .. c0+3: chunk c0/32, offset c0%32
+                unsigned short* dst = prow + (size_t)(c0 >> 5) * NT * 32 + (c0 & 31);
+#pragma unroll
+                for (int pl = 0; pl < NT; ++pl) {
+                    unsigned short h[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        h[e] = f32_to_bf16_bits(r[e]);
+                        r[e] -= bf16_bits_to_f32(h[e]);
+                    }
+                    *reinterpret_cast<uint2*>(dst + pl * 32) =
+                        make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+                }
+            }
+        }
+        if (lane == 0) {
+            mean[row] = mu;
+            rstd[row] = rs;
+        }
+    }
+}
+
 // dx = rstd * (g*dy - mean_c(g*dy) - xhat * mean_c(g*dy*xhat)) (+ dres);  partial[blk] = [dg | db]
 template <typename T>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
@@ -309,6 +371,24 @@ int pa2d_layernorm_fwd(const float* x, const float* g, const float* b, float* y,
 int pa2d_layernorm_fwd_bf16(const void* x, const float* g, const float* b, void* y, float* mean, float* rstd, int rows,
                             int C, float eps, hipStream_t st) {
     return ln_fwd_t<bf16_t>((const bf16_t*)x, g, b, (bf16_t*)y, mean, rstd, rows, C, eps, st);
+}
+
+// planes: pa2d_planes_bytes(rows, C, engine) bytes; engine PA2D_ENGINE_SPLIT (3 planes) or PA2D_ENGINE_BF16 (1 plane)
+int pa2d_layernorm_fwd_planes(const float* x, const float* g, const float* b, void* planes, float* mean, float* rstd,
+                              int rows, int C, float eps, int engine, hipStream_t st) {
+    if ((C & 31) || C > 256 * LN_MAXV) return PA2D_ERR_UNSUPPORTED;
+    if (engine != 1 && engine != 2) return PA2D_ERR_ARG;
+    if (rows <= 0) return PA2D_OK;
+    int grid = ceil_div(rows, 4);
+    if (grid > 8192) grid = 8192;
+    if (engine == 1)
+        hipLaunchKernelGGL((layernorm_fwd_planes_kernel<3>), dim3(grid), dim3(256), 0, st, x, g, b, (unsigned short*)planes,
+                           mean, rstd, rows, C, eps);
+    else
+        hipLaunchKernelGGL((layernorm_fwd_planes_kernel<1>), dim3(grid), dim3(256), 0, st, x, g, b, (unsigned short*)planes,
+                           mean, rstd, rows, C, eps);
+    PA2D_CHECK_LAUNCH();
+    return PA2D_OK;
 }
 
 size_t pa2d_layernorm_bwd_workspace(int rows, int C) { return sizeof(float) * ((size_t)row_blocks(rows) + 1) * 2 * C; }

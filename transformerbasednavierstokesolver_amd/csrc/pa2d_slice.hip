@@ -347,6 +347,10 @@ struct SliceBwdParams {
     const float* o; const float* ds; const float* dn;   // [B,heads,M,D] x2, [B,heads,M]
     void* dxm; long long lddx;          // outputs
     void* dfm; long long lddf;
+    void* planes; unsigned planes_bytes; int planes_nt;   // planes_nt > 0: [dX | dF] is written ONLY as the bf16 plane image
+                                        // [row][2C/32][nt][32] the conv GEMMs stage (no fp32 dxm / dfm), and the
+                                        // column sums of dX / dF (= the conv bias gradients) go to the block record
+    int stride;                         // floats per block record: M*D (dWs) + M (dbs) + 1 (dtau) + 2*D (dbx | dbf)
     float* part;                        // per block: [M*D (dWs) | M (dbs) | 1 (dtau)]
     int B, N, heads, M, nchunk, ppc;
     unsigned x_bytes, f_bytes, dy_bytes, dx_bytes, df_bytes;
@@ -356,7 +360,7 @@ struct SliceBwdParams {
 // Backward phase C (per point): recompute W, then
 //   dW = dY.O^T + F.dS^T + dn ; dL = W*(dW - rowsum(dW*W)) ; dF = W.dS ; dX = dL.Ws/tau
 //   dWs += (dL/tau)^T.X ; dbs += sum dL/tau ; dtau -= sum(dL*L)/tau
-template <int D, int MT, typename T>
+template <int D, int MT, typename T, int PL = 0>
 __global__ __launch_bounds__(256) void slice_bwd_kernel(const SliceBwdParams p) {
     constexpr int KS = SCfg<D>::KS, DT = SCfg<D>::DT, VEC = SCfg<D>::VEC, NV = SCfg<D>::NV;
     constexpr unsigned ES = Act<T>::ES;
@@ -405,6 +409,13 @@ __global__ __launch_bounds__(256) void slice_bwd_kernel(const SliceBwdParams p) 
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) wsacc[mt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    float bxs[DT][4], bfs[DT][4];            // PL: column sums of dX / dF over this lane's points
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bxs[dt][r] = bfs[dt][r] = 0.f;
+    const __amdgpu_buffer_rsrc_t rpl = make_rsrc_v(PL ? p.planes : nullptr, PL ? p.planes_bytes : 0u);
+    const int Ctot = p.heads * D;
     float* const myT = TL + wave * 16 * TP;
     const int p_begin = chunk * p.ppc;
     const int p_end = min(p.N, p_begin + p.ppc);
@@ -541,11 +552,41 @@ __global__ __launch_bounds__(256) void slice_bwd_kernel(const SliceBwdParams p) 
         for (int dt = 0; dt < DT; ++dt) {
             const int d = 16 * dt + 4 * kq;
             const bool ok = pv && d < D;
-            Act<T>::bst4(rdf, ok ? (row0 + pt) * lddf4 + hcol + d * ES : OOB_OFF,
-                         make_float4(facc[dt][0], facc[dt][1], facc[dt][2], facc[dt][3]));
-            Act<T>::bst4(rdx, ok ? (row0 + pt) * lddx4 + hcol + d * ES : OOB_OFF,
-                         make_float4(xacc[dt][0] * inv_tau, xacc[dt][1] * inv_tau, xacc[dt][2] * inv_tau,
-                                     xacc[dt][3] * inv_tau));
+            const float4 fo = make_float4(facc[dt][0], facc[dt][1], facc[dt][2], facc[dt][3]);
+            const float4 xo = make_float4(xacc[dt][0] * inv_tau, xacc[dt][1] * inv_tau, xacc[dt][2] * inv_tau,
+                                          xacc[dt][3] * inv_tau);
+            if constexpr (PL == 0) {
+                Act<T>::bst4(rdf, ok ? (row0 + pt) * lddf4 + hcol + d * ES : OOB_OFF, fo);
+                Act<T>::bst4(rdx, ok ? (row0 + pt) * lddx4 + hcol + d * ES : OOB_OFF, xo);
+            } else {
+                // plane image of the [rows, 2C] tensor [dX | dF]: 4 consecutive channels = 8 bytes in each plane
+                const int cx = hh * D + d, cf = Ctot + cx;
+                const unsigned rowb = (row0 + pt) * (unsigned)((2 * Ctot / 32) * PL * 64);
+                const unsigned ox = ok ? rowb + (unsigned)(((cx >> 5) * PL) * 64 + (cx & 31) * 2) : OOB_OFF;
+                const unsigned of_ = ok ? rowb + (unsigned)(((cf >> 5) * PL) * 64 + (cf & 31) * 2) : OOB_OFF;
+                const float xv[4] = {xo.x, xo.y, xo.z, xo.w}, fv[4] = {fo.x, fo.y, fo.z, fo.w};
+                float xr[4] = {xv[0], xv[1], xv[2], xv[3]}, fr[4] = {fv[0], fv[1], fv[2], fv[3]};
+                typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
+#pragma unroll
+                for (int q = 0; q < PL; ++q) {
+                    unsigned short hx[4], hf[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        hx[e] = f32_to_bf16_bits(xr[e]);
+                        hf[e] = f32_to_bf16_bits(fr[e]);
+                        xr[e] -= bf16_bits_to_f32(hx[e]);
+                        fr[e] -= bf16_bits_to_f32(hf[e]);
+                    }
+                    const u32x2_ qx = {(unsigned)hx[0] | ((unsigned)hx[1] << 16), (unsigned)hx[2] | ((unsigned)hx[3] << 16)};
+                    const u32x2_ qf = {(unsigned)hf[0] | ((unsigned)hf[1] << 16), (unsigned)hf[2] | ((unsigned)hf[3] << 16)};
+                    __builtin_amdgcn_raw_buffer_store_b64(qx, rpl, ox == OOB_OFF ? OOB_OFF : ox + q * 64u, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(qf, rpl, of_ == OOB_OFF ? OOB_OFF : of_ + q * 64u, 0, 0);
+                }
+                if (ok) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { bxs[dt][e] += xv[e]; bfs[dt][e] += fv[e]; }
+                }
+            }
         }
         // dWs += dL^T . X : transpose the 16 x M tile of dL through wave-private LDS so that the
         // slice index lands on the lane (A operand i = m, k = point)
@@ -584,6 +625,13 @@ __global__ __launch_bounds__(256) void slice_bwd_kernel(const SliceBwdParams p) 
     float* const rW = red;
     float* const rB = red + MP * DP;
     float* const rT = rB + MP;
+    float* const rX = rT + 4;                // [2][DP] column sums of dX | dF (PL only)
+    if constexpr (PL != 0) {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { bxs[dt][r] = row16_sum(bxs[dt][r]); bfs[dt][r] = row16_sum(bfs[dt][r]); }
+    }
     __syncthreads();
     for (int wv = 0; wv < 4; ++wv) {
         if (wave == wv) {
@@ -600,13 +648,27 @@ __global__ __launch_bounds__(256) void slice_bwd_kernel(const SliceBwdParams p) 
                     if (li == 0) rB[m] = (wv == 0 ? 0.f : rB[m]) + dbacc[mt][r];
                 }
             if (lane == 0) rT[0] = (wv == 0 ? 0.f : rT[0]) + dtacc;
+            if constexpr (PL != 0) {
+                if (li == 0) {
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int d = 16 * dt + 4 * kq + r;
+                            rX[d] = (wv == 0 ? 0.f : rX[d]) + bxs[dt][r];
+                            rX[DP + d] = (wv == 0 ? 0.f : rX[DP + d]) + bfs[dt][r];
+                        }
+                }
+            }
         }
         __syncthreads();
     }
-    float* po = p.part + (size_t)bid * (p.M * D + p.M + 1);
+    float* po = p.part + (size_t)bid * p.stride;
     for (int i = tid; i < p.M * D; i += 256) po[i] = rW[(i / D) * DP + (i % D)] * inv_tau;
     for (int i = tid; i < p.M; i += 256) po[p.M * D + i] = rB[i] * inv_tau;
     if (tid == 0) po[p.M * D + p.M] = -rT[0] * inv_tau;
+    if constexpr (PL != 0)
+        for (int i = tid; i < 2 * D; i += 256) po[p.M * D + p.M + 1 + i] = rX[(i / D) * DP + (i % D)];
 }
 
 // dtemperature[h] = mask(0.1 <= t <= 5) * sum over (b, chunk) of the per-block dtau partials
@@ -621,6 +683,20 @@ __global__ void dtau_finalize_kernel(const float* __restrict__ part, const float
     const float t = temperature[hh];
     const float v = (!clamp || (t >= 0.1f && t <= 5.0f)) ? s : 0.f;
     dtemp[hh] = accumulate ? dtemp[hh] + v : v;
+}
+
+// conv bias gradients from the block records of the planes variant: dbx[h*D+d] (+)= sum over (b, chunk) of record[off + d],
+// dbf likewise at off + D
+__global__ void conv_bias_finalize_kernel(const float* __restrict__ part, float* __restrict__ dbx, float* __restrict__ dbf,
+                                          int B, int heads, int nchunk, int stride, int off, int D, int accumulate) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 2 * heads * D) return;
+    const int which = idx / (heads * D), c = idx - which * heads * D, hh = c / D, d = c - hh * D;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b)
+        for (int ch = 0; ch < nchunk; ++ch) s += part[(size_t)((b * heads + hh) * nchunk + ch) * stride + off + which * D + d];
+    float* dst = which ? dbf : dbx;
+    dst[c] = accumulate ? dst[c] + s : s;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -638,22 +714,25 @@ static void launch_deslice_t(const DesliceParams& p, int grid, hipStream_t st, b
 template <int D, int MT>
 static size_t bwd_smem_bytes() {
     constexpr int DT = SCfg<D>::DT, MP = 16 * MT, DP = 16 * DT, P = DP + 4, TP = MP + 4;
-    static_assert(MP * DP + MP + 4 <= 3 * MP * P, "reduction scratch must fit in the aliased region");
+    static_assert(MP * DP + MP + 4 + 2 * DP <= 3 * MP * P, "reduction scratch must fit in the aliased region");
     return sizeof(float) * (size_t)(3 * MP * P + 2 * MP + 4 * 16 * TP);
+}
+template <int D, int MT, typename T, int PL>
+static int launch_bwd_one(const SliceBwdParams& p, int grid, hipStream_t st, size_t smem) {
+    if (smem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&slice_bwd_kernel<D, MT, T, PL>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL((slice_bwd_kernel<D, MT, T, PL>), dim3(slice_grid(grid)), dim3(256), smem, st, p);
+    return PA2D_OK;
 }
 template <int D, int MT>
 static int launch_bwd_t(const SliceBwdParams& p, int grid, hipStream_t st, bool bf) {
     const size_t smem = bwd_smem_bytes<D, MT>();
-    if (smem > 64 * 1024) {
-        hipError_t e = bf ? hipFuncSetAttribute(reinterpret_cast<const void*>(&slice_bwd_kernel<D, MT, bf16_t>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)
-                          : hipFuncSetAttribute(reinterpret_cast<const void*>(&slice_bwd_kernel<D, MT, float>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-        if (e != hipSuccess) return (int)e;
-    }
-    if (bf) hipLaunchKernelGGL((slice_bwd_kernel<D, MT, bf16_t>), dim3(slice_grid(grid)), dim3(256), smem, st, p);
-    else hipLaunchKernelGGL((slice_bwd_kernel<D, MT, float>), dim3(slice_grid(grid)), dim3(256), smem, st, p);
-    return PA2D_OK;
+    if (p.planes_nt == 3) return bf ? PA2D_ERR_ARG : launch_bwd_one<D, MT, float, 3>(p, grid, st, smem);
+    if (p.planes_nt == 1) return bf ? PA2D_ERR_ARG : launch_bwd_one<D, MT, float, 1>(p, grid, st, smem);
+    return bf ? launch_bwd_one<D, MT, bf16_t, 0>(p, grid, st, smem) : launch_bwd_one<D, MT, float, 0>(p, grid, st, smem);
 }
 
 #define DISPATCH_MT(D_, CALL)                                    \
@@ -796,7 +875,8 @@ static int slice_bwd_impl(const void* xm, long long ldx, const void* fm, long lo
                           const float* dn, void* dxm, long long lddx, void* dfm, long long lddf, float* dws, float* dbs,
                           float* dtemperature, void* ws_buf, size_t ws_bytes, int B, int N, int heads, int D, int M,
                           int clamp_temperature, int accumulate, hipStream_t st, hipEvent_t ev_start,
-                          hipEvent_t ev_stop, bool bf) {
+                          hipEvent_t ev_stop, bool bf, void* planes = nullptr, int planes_nt = 0, float* dbx = nullptr,
+                          float* dbf = nullptr) {
     const int mt = mt_for(M);
     if ((ldx & 3) || (ldf & 3) || (lddy & 3) || (lddx & 3) || (lddf & 3) || (D & 7)) return PA2D_ERR_ARG;
     if (B <= 0 || N <= 0) {
@@ -814,6 +894,16 @@ static int slice_bwd_impl(const void* xm, long long ldx, const void* fm, long lo
     p.xcd_map = slice_xcd_map(); p.xcd_map = slice_xcd_map();
     p.nchunk = pa2d_slice_nchunk(B, N, heads);
     p.ppc = ppc_for(N, p.nchunk);
+    p.stride = M * D + M + 1 + 2 * D;
+    p.planes = planes; p.planes_nt = planes ? planes_nt : 0; p.planes_bytes = 0;
+    if (planes) {
+        if ((planes_nt != 1 && planes_nt != 3) || ((heads * D) & 31) || (D & 3)) return PA2D_ERR_UNSUPPORTED;
+        const unsigned long long pb = (unsigned long long)B * N * (2ull * heads * D) * planes_nt * 2ull;
+        if (pb >= 0xFFFFFFF0ull) return PA2D_ERR_UNSUPPORTED;
+        p.planes_bytes = (unsigned)pb;
+        if (!dxm) { p.dxm = const_cast<void*>(xm); lddx = ldx; p.lddx = ldx; }     // descriptors need a base; nothing is stored there
+        if (!dfm) { p.dfm = const_cast<void*>(fm); lddf = ldf; p.lddf = ldf; }
+    }
     {
         const unsigned long long rows = (unsigned long long)B * N, w = (unsigned long long)heads * D;
         const unsigned long long e[5] = {((rows - 1) * ldx + w) * es, ((rows - 1) * ldf + w) * es,
@@ -832,8 +922,8 @@ static int slice_bwd_impl(const void* xm, long long ldx, const void* fm, long lo
     if (rc) return rc;
     PA2D_CHECK_LAUNCH();
     if (ev_stop && hipEventRecord(ev_stop, st) != hipSuccess) return PA2D_ERR_ARG;
-    // sum the per-block records [dWs | dbs | dtau] straight into dws / dbs (the dtau column is finalised below)
-    const int stride = M * D + M + 1;
+    // sum the per-block records [dWs | dbs | dtau | ..] straight into dws / dbs (the dtau column is finalised below)
+    const int stride = p.stride;
     ReduceSegs segs;
     segs.nseg = 2;
     segs.begin[0] = 0; segs.begin[1] = (long long)M * D; segs.begin[2] = (long long)M * D + M;
@@ -844,6 +934,11 @@ static int slice_bwd_impl(const void* xm, long long ldx, const void* fm, long lo
     hipLaunchKernelGGL(dtau_finalize_kernel, dim3(ceil_div(heads, 64)), dim3(64), 0, st, p.part, temperature,
                        dtemperature, B, heads, p.nchunk, stride, M * D + M, clamp_temperature, accumulate);
     PA2D_CHECK_LAUNCH();
+    if (planes && dbx && dbf) {
+        hipLaunchKernelGGL(conv_bias_finalize_kernel, dim3(ceil_div(2 * heads * D, 256)), dim3(256), 0, st, p.part, dbx, dbf, B,
+                           heads, p.nchunk, stride, M * D + M + 1, D, accumulate);
+        PA2D_CHECK_LAUNCH();
+    }
     return PA2D_OK;
 }
 
@@ -877,7 +972,7 @@ int pa2d_deslice_fwd_bf16(const void* xm, long long ldx, const float* o, const f
 
 size_t pa2d_slice_bwd_workspace(int B, int N, int heads, int D, int M) {
     const int nchunk = pa2d_slice_nchunk(B, N, heads);
-    return sizeof(float) * ((size_t)B * heads * nchunk + 1) * ((size_t)M * D + M + 1);
+    return sizeof(float) * ((size_t)B * heads * nchunk + 1) * ((size_t)M * D + M + 1 + 2 * D);
 }
 
 int pa2d_slice_bwd_points(const float* xm, long long ldx, const float* fm, long long ldf, const float* dy,
@@ -899,6 +994,23 @@ int pa2d_slice_bwd_points_bf16(const void* xm, long long ldx, const void* fm, lo
     return slice_bwd_impl(xm, ldx, fm, ldf, dy, lddy, ws, bs, temperature, o, ds, dn, dxm, lddx, dfm, lddf, dws, dbs,
                           dtemperature, ws_buf, ws_bytes, B, N, heads, D, M, clamp_temperature, accumulate, st, ev_start,
                           ev_stop, true);
+}
+
+// Same, but [dX | dF] leaves ONLY as the bf16 plane image the conv GEMMs of `engine` stage (NT = 3 planes for
+// PA2D_ENGINE_SPLIT, 1 for PA2D_ENGINE_BF16; pa2d_planes_bytes(B*N, 2*heads*D, engine) bytes) — no fp32 tensor, no split
+// pre-pass in the conv backward — and the conv bias gradients dbx / dbf [heads*D] (column sums of dX / dF) come out of the
+// same partial-sum records.
+int pa2d_slice_bwd_points_planes(const float* xm, long long ldx, const float* fm, long long ldf, const float* dy,
+                                 long long lddy, const float* ws, const float* bs, const float* temperature,
+                                 const float* o, const float* ds, const float* dn, void* dxf_planes, float* dbx,
+                                 float* dbf, float* dws, float* dbs, float* dtemperature, void* ws_buf, size_t ws_bytes,
+                                 int B, int N, int heads, int D, int M, int clamp_temperature, int accumulate, int engine,
+                                 hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    if (engine != 1 && engine != 2) return PA2D_ERR_ARG;
+    if (!dxf_planes || !dbx || !dbf) return PA2D_ERR_ARG;
+    return slice_bwd_impl(xm, ldx, fm, ldf, dy, lddy, ws, bs, temperature, o, ds, dn, nullptr, 0, nullptr, 0, dws, dbs,
+                          dtemperature, ws_buf, ws_bytes, B, N, heads, D, M, clamp_temperature, accumulate, st, ev_start,
+                          ev_stop, false, dxf_planes, engine == 2 ? 1 : 3, dbx, dbf);
 }
 
 }  // extern "C"

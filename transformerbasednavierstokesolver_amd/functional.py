@@ -30,16 +30,20 @@ def _ret(targets, grads):
 
 
 # ------------------------------------------------------------------------------ Physics-Attention
-def attn_forward(xn, P, res, H, W, heads, engine=None):
+def attn_forward(xn, P, res, H, W, heads, engine=None, xn_planes=None, shape=None):
     """xn [B,N,C] (already layer-normed).  P: dict of parameter tensors.  Returns (out, saved).
     H is None -> irregular-mesh variant (Physics_Attention.py:6-57): Linear projections, no
-    temperature clamp; otherwise the structured-mesh variant (3x3 conv projections, clamp)."""
-    B, N, C = xn.shape
+    temperature clamp; otherwise the structured-mesh variant (3x3 conv projections, clamp).
+    xn_planes (structured, bf16 engines): the LayerNorm output exists only as the conv's bf16 plane image
+    (ops.layernorm_fwd_planes); `xn` is then None and `shape` = (B, N, C)."""
+    B, N, C = xn.shape if xn is not None else shape
     D = C // heads
     M = P["ws"].shape[0]
     temp = P["temperature"].reshape(heads).contiguous()
     structured = H is not None
-    if structured:
+    if xn_planes is not None:
+        xf = ops.conv3x3x2_fwd_planes(xn_planes, P["wx"], P["bx"], P["wf"], P["bf"], B, H, W, engine)
+    elif structured:
         xf = ops.conv3x3x2_fwd(xn, P["wx"], P["bx"], P["wf"], P["bf"], H, W, engine=engine)    # [B,N,2C]
     else:   # both Linear(C, C) projections as ONE GEMM with the weights stacked along the output dim
         wcat, bcat = torch.cat((P["wx"], P["wf"]), 0), torch.cat((P["bx"], P["bf"]), 0)
@@ -50,13 +54,16 @@ def attn_forward(xn, P, res, H, W, heads, engine=None):
     y = ops.deslice_fwd(xf, 2 * C, 0, o, P["ws"], P["bs"], temp, B, N, heads, D, M, clamp=structured)  # [B,N,C]
     out, _ = ops.linear_fwd(y.view(B * N, C), P["wo"], P["bo"],
                             res=None if res is None else res.reshape(B * N, C), engine=engine)
-    return out.view(B, N, C), (xn, xf, s, nrm, o, y, temp)
+    return out.view(B, N, C), (xn if xn_planes is None else xn_planes, xf, s, nrm, o, y, temp)
 
 
-def attn_backward(saved, P, dout, H, W, heads, need_dx=True, engine=None, targets=None):
-    """`targets`: dict ATTN_KEYS -> gradient buffer to ADD into (structured meshes), or None (fresh tensors)."""
+def attn_backward(saved, P, dout, H, W, heads, need_dx=True, engine=None, targets=None, planes=False):
+    """`targets`: dict ATTN_KEYS -> gradient buffer to ADD into (structured meshes), or None (fresh tensors).
+    `planes`: saved[0] is the plane image of the LayerNorm output; the slice backward then emits [dX | dF] as planes too
+    (plus the conv bias gradients) and the conv backward consumes both images directly."""
     xn, xf, s, nrm, o, y, temp = saved
-    B, N, C = xn.shape
+    B, N, C2 = xf.shape
+    C = C2 // 2
     D = C // heads
     M = P["ws"].shape[0]
     d2 = dout.reshape(B * N, C)
@@ -68,6 +75,16 @@ def attn_backward(saved, P, dout, H, W, heads, need_dx=True, engine=None, target
     dopart, _ = ops.slice_scatter(xf, 2 * C, 0, dy, C, 0, P["ws"], P["bs"], temp, B, N, heads, D, M,
                                   want_norm=False, clamp=structured)
     ds, dn, dwq, dwk, dwv = ops.token_attn_bwd(s, nrm, P["wq"], P["wk"], P["wv"], dopart, into=t("wq", "wk", "wv"))
+    if planes:
+        dxfp, dbx, dbf, dws, dbs, dtemp = ops.slice_bwd_points_planes(xf, dy, P["ws"], P["bs"], temp, o, ds, dn, B, N, heads,
+                                                                      D, M, engine, clamp=True,
+                                                                      into=t("bx", "bf", "ws", "bs", "temperature"))
+        dxn, dwx, dwf = ops.conv3x3x2_bwd_planes(dxfp, xn, P["wx"], P["wf"], B, H, W, engine, need_dx=need_dx,
+                                                 into=t("wx", "wf"))
+        if T is not None:
+            return dxn, None
+        return dxn, dict(temperature=dtemp.view(1, heads, 1, 1), wx=dwx, bx=dbx, wf=dwf, bf=dbf, ws=dws, bs=dbs,
+                         wq=dwq, wk=dwk, wv=dwv, wo=dwo, bo=dbo)
     dxf, dws, dbs, dtemp = ops.slice_bwd_points(xf, dy, P["ws"], P["bs"], temp, o, ds, dn, B, N, heads, D, M,
                                                 clamp=structured, into=t("ws", "bs", "temperature"))
     if structured:
@@ -213,9 +230,16 @@ class AttnBranchFn(Function):
         ctx.params, ctx.ln_params = params, (ln_w, ln_b)
         fx2d = fx.detach().reshape(-1, shp[-1]).contiguous()
         ln_w, ln_b = ln_w.detach().contiguous(), ln_b.detach().contiguous()
-        xn, mean, rstd = ops.layernorm_fwd(fx2d, ln_w, ln_b)
         P = dict(zip(ATTN_KEYS, (p.detach().contiguous() for p in params)))
-        out, saved = attn_forward(xn.view(shp), P, fx2d.view(shp), H, W, heads, engine)
+        # bf16 engines on fp32 storage: LayerNorm writes the conv's operand planes directly (no fp32 xn, no pre-pass)
+        ctx.planes = (H is not None and fx2d.dtype == torch.float32 and len(shp) == 3
+                      and ops.conv_planes_mask(shp[0], H, W, shp[2], engine) == 7)
+        if ctx.planes:
+            xnp, mean, rstd = ops.layernorm_fwd_planes(fx2d, ln_w, ln_b, engine)
+            out, saved = attn_forward(None, P, fx2d.view(shp), H, W, heads, engine, xn_planes=xnp, shape=tuple(shp))
+        else:
+            xn, mean, rstd = ops.layernorm_fwd(fx2d, ln_w, ln_b)
+            out, saved = attn_forward(xn.view(shp), P, fx2d.view(shp), H, W, heads, engine)
         ctx.P, ctx.saved, ctx.geom, ctx.ln = P, saved, (H, W, heads, engine), (fx2d, mean, rstd, ln_w)
         return out
 
@@ -225,7 +249,7 @@ class AttnBranchFn(Function):
         fx2d, mean, rstd, ln_w = ctx.ln
         dout = dout.contiguous()
         dxn, g = attn_backward(ctx.saved, ctx.P, dout, H, W, heads, need_dx=True, engine=engine,
-                               targets=_attn_targets(ctx.params, H is not None))
+                               targets=_attn_targets(ctx.params, H is not None), planes=ctx.planes)
         tl = grad_targets(ctx.ln_params)
         dfx, dg, db = ops.layernorm_bwd(dxn.reshape(fx2d.shape), fx2d, mean, rstd, ln_w, dres=dout.reshape(fx2d.shape),
                                         into=tl)

@@ -324,6 +324,82 @@ def conv3x3x2_bwd(dout, xn, wx, wf, H, W, need_dx=True, engine=None, into=None):
     return dxn, dwx, dbx, dwf, dbf
 
 
+# ---------------------------------------------------------------------------------------------- operand planes
+def conv_planes_mask(B, H, W, Cc, engine):
+    """7 when `engine` consumes every conv operand at this shape as bf16 planes (then LayerNorm / slice backward can emit
+    the planes directly: layernorm_fwd_planes, slice_bwd_points_planes, conv3x3x2_fwd/bwd_planes)."""
+    eng = _abi_engine(engine)
+    return _L().pa2d_conv3x3x2_planes_mask(B, H, W, Cc, eng) if eng in (ENGINE_SPLIT, ENGINE_BF16) else 0
+
+
+def _planes(rows, Cc, eng, like):
+    return torch.empty(_L().pa2d_planes_bytes(rows, Cc, eng), dtype=torch.uint8, device=like.device)
+
+
+def layernorm_fwd_planes(x2d, gamma, beta, engine, eps=LN_EPS):
+    """LayerNorm whose output exists ONLY as the bf16 plane image the conv GEMMs stage.  Returns (planes, mean, rstd)."""
+    _chk(x2d, gamma, beta)
+    rows, Cc = x2d.shape
+    eng = _abi_engine(engine)
+    planes = _planes(rows, Cc, eng, x2d)
+    mean = torch.empty(rows, dtype=torch.float32, device=x2d.device)
+    rstd = torch.empty_like(mean)
+    _lib.check(_L().pa2d_layernorm_fwd_planes(_p(x2d), _p(gamma), _p(beta), planes.data_ptr(), _p(mean), _p(rstd), rows,
+                                              Cc, eps, eng, _stream()), "layernorm_fwd_planes")
+    return planes, mean, rstd
+
+
+def conv3x3x2_fwd_planes(xn_planes, wx, bx, wf, bf, B, H, W, engine):
+    """[x_mid | fx_mid] [B, H*W, 2C] fp32 from the plane image of the LayerNorm output."""
+    _chk(wx, bx, wf, bf)
+    Cc = wx.shape[0]
+    eng = _abi_engine(engine)
+    out = torch.empty(B, H * W, 2 * Cc, dtype=torch.float32, device=wx.device)
+    pre = _conv_pack(wx, wf, B, H, W, Cc, 0, eng)
+    nb = _L().pa2d_conv3x3x2_pack_bytes(Cc)
+    ws = _ws(nb, wx)
+    e0, e1 = _events("conv")
+    _lib.check(_L().pa2d_conv3x3x2_fwd_planes(xn_planes.data_ptr(), _p(wx), _p(bx), _p(wf), _p(bf), _p(out), pre,
+                                              ws.data_ptr(), nb, B, H, W, Cc, eng, _stream(), e0, e1),
+               "conv3x3x2_fwd_planes")
+    return out
+
+
+def conv3x3x2_bwd_planes(dout_planes, xn_planes, wx, wf, B, H, W, engine, need_dx=True, into=None):
+    """(dxn, dwx, dwf) from plane images of dOut and X; `into` = (dwx, dwf) buffers to accumulate into."""
+    _chk(wx, wf)
+    Cc = wx.shape[0]
+    eng = _abi_engine(engine)
+    dxn = torch.empty(B, H * W, Cc, dtype=torch.float32, device=wx.device) if need_dx else None
+    (dwx, dwf), acc = _grad_outputs(into, (wx.shape, wf.shape), wx)
+    nb = _L().pa2d_conv3x3x2_workspace_planes(B, H, W, Cc, eng)
+    ws = _ws(nb, wx)
+    pre = _conv_pack(wx, wf, B, H, W, Cc, 1, eng) if need_dx else 0
+    e0, e1 = _events("conv") if need_dx else (0, 0)
+    _lib.check(_L().pa2d_conv3x3x2_bwd_planes(dout_planes.data_ptr(), xn_planes.data_ptr(), _p(wx), _p(wf), _p(dxn), _p(dwx),
+                                              _p(dwf), pre, ws.data_ptr(), nb, B, H, W, Cc, acc, eng, _stream(), e0, e1),
+               "conv3x3x2_bwd_planes")
+    return dxn, dwx, dwf
+
+
+def slice_bwd_points_planes(xf, dy, ws_w, bs, temperature, o, ds, dn, B, N, heads, D, M, engine, clamp=True, into=None):
+    """slice_bwd_points whose [dX | dF] leaves only as the plane image for the conv backward; also returns the conv bias
+    gradients.  Returns (dxf_planes, dbx, dbf, dws, dbs, dtemperature); `into` = (dbx, dbf, dws, dbs, dtemperature)."""
+    _chk(xf, dy, ws_w, bs, temperature, o, ds, dn)
+    Cc = heads * D
+    eng = _abi_engine(engine)
+    planes = _planes(B * N, 2 * Cc, eng, xf)
+    (dbx, dbf, dws, dbs, dtemp), acc = _grad_outputs(into, ((Cc,), (Cc,), ws_w.shape, bs.shape, (heads,)), xf)
+    nb = _L().pa2d_slice_bwd_workspace(B, N, heads, D, M)
+    ws = _ws(nb, xf)
+    e0, e1 = _events("slice_bwd")
+    _lib.check(_L().pa2d_slice_bwd_points_planes(_p(xf), 2 * Cc, _p(xf, Cc), 2 * Cc, _p(dy), Cc, _p(ws_w), _p(bs),
+                                                 _p(temperature), _p(o), _p(ds), _p(dn), planes.data_ptr(), _p(dbx), _p(dbf),
+                                                 _p(dws), _p(dbs), _p(dtemp), ws.data_ptr(), nb, B, N, heads, D, M,
+                                                 int(clamp), acc, eng, _stream(), e0, e1), "slice_bwd_points_planes")
+    return planes, dbx, dbf, dws, dbs, dtemp
+
+
 def slice_nchunk(B, N, heads):
     return _L().pa2d_slice_nchunk(B, N, heads)
 
