@@ -70,6 +70,7 @@ def _check_linear(dev, M, N, K, act, engine, FWD_TOL, BWD_TOL):
     acc_w, acc_b = torch.full_like(dwk, 0.5), torch.full_like(dbk, -0.25)
     ops.linear_bwd_weight(dy.to(dev), x.to(dev), engine=engine, into=(acc_w, acc_b))
     assert rel_l2(acc_w - 0.5, dwk) < 1e-5 and rel_l2(acc_b + 0.25, dbk) < 1e-5
+    assert rel_l2(dbk, dy.double().sum(0)) < BWD_TOL          # the bias gradient rides in the weight-gradient GEMM
     if act is None:
         assert rel_l2(dwk, wd.grad) < BWD_TOL and rel_l2(dbk, bd.grad) < BWD_TOL
         assert rel_l2(dxk, xd.grad) < BWD_TOL

@@ -156,8 +156,7 @@ int pa2d_gemm_bwd_data(const float* dy, long long lddy, const float* w, long lon
 size_t pa2d_gemm_bwd_weight_workspace(int M, int N, int K, int engine) {
     (void)engine;
     const MCPlan pl = plan_mc(N, K, M);
-    size_t a = pl.slab_floats, b = (size_t)colsum_blocks(M) * N;
-    return (a > b ? a : b) * sizeof(float);
+    return (pl.slab_floats + (size_t)pl.splits * N) * sizeof(float);      // [slabs | per-split column sums of dy]
 }
 
 // dw[N,K] (+)= dy[M,N]^T . x[M,K] ; db[N] (+)= column sums of dy (db may be NULL).  accumulate != 0: add to what dw / db
@@ -172,11 +171,13 @@ int pa2d_gemm_bwd_weight(const float* dy, long long lddy, const float* x, long l
     }
     if (ws_bytes < pa2d_gemm_bwd_weight_workspace(M, N, K, engine)) return PA2D_ERR_WORKSPACE;
     const MCPlan pl = plan_mc(N, K, M);
-    int rc = launch_mc(dy, lddy, N, x, ldx, K, M, false, 0, 0, 0, (float*)ws, pl, engine, st);
+    // the bias gradient (column sums of dy) rides in the GEMM: the workgroups of column tile 0 sum the dy tiles they stage
+    float* cs = db ? (float*)ws + pl.slab_floats : nullptr;
+    int rc = launch_mc(dy, lddy, N, x, ldx, K, M, false, 0, 0, 0, (float*)ws, pl, engine, st, cs);
     if (rc) return rc;
     rc = launch_reduce((const float*)ws, pl.splits, (long long)N * K, dw, nullptr, 0, 0, 0, st, accumulate);
     if (rc) return rc;
-    if (db) rc = launch_colsum(dy, lddy, M, N, db, (float*)ws, st, nullptr, 0, accumulate);
+    if (db) rc = launch_reduce(cs, pl.splits, N, db, nullptr, 0, 0, 0, st, accumulate);
     return rc;
 }
 

@@ -118,6 +118,8 @@ struct MCParams {
     int Mk, chunks_per_split, splits;
     int H, W, Cin;   // im2col view of B: image [B,H,W,Cin] with pixel pitch ldb, j = tap*Cin + ci
     unsigned a_bytes, b_bytes;
+    float* colsum;   // optional [splits][Mi]: per-split column sums of A (= the bias gradient of a linear layer), produced
+                     // by the workgroups of column tile 0 from the A tiles they stage anyway; NULL = off
 };
 struct MCPlan { int big; int splits; int chunks_per_split; size_t slab_floats; };
 struct KCTile { int bm, bn, bk; };
@@ -138,7 +140,7 @@ int launch_conv_halo(const KCParams& p, hipStream_t st);
 // weight-gradient engine and reductions (pa2d_gemm_mc.hip)
 MCPlan plan_mc(int Mi, int Nj, int Mk);
 int launch_mc(const float* A, long long lda, int Mi, const float* B, long long ldb, int Nj, int Mk, bool im2col,
-              int H, int W, int Cin, float* slab, const MCPlan& pl, int engine, hipStream_t st);
+              int H, int W, int Cin, float* slab, const MCPlan& pl, int engine, hipStream_t st, float* colsum = nullptr);
 // accumulate != 0: out += sum of slabs (gradient accumulation straight into the caller's buffer)
 int launch_reduce(const float* slab, int nslab, long long count, float* out, float* out2, int mode, int C, int Cin,
                   hipStream_t st, int accumulate = 0);

@@ -97,10 +97,14 @@ __global__ __launch_bounds__(256, 2) void gemm_mc_kernel(const MCParams p) {
             }                                                                                             \
         }                                                                                                 \
     }
+    const bool do_cs = p.colsum != nullptr && tj == 0;      // column sums of A: once per (split, row tile)
+    float4 cs = make_float4(0.f, 0.f, 0.f, 0.f);
 #define MC_STORE(buf_)                                                                                    \
     {                                                                                                     \
-        _Pragma("unroll") for (int s = 0; s < A_IT; ++s)                                                  \
+        _Pragma("unroll") for (int s = 0; s < A_IT; ++s) {                                                \
             *reinterpret_cast<float4*>(As + (buf_) * BK * BM + (a_r + s * A_RPP) * BM + a_c) = ra[s];     \
+            if (do_cs) { cs.x += ra[s].x; cs.y += ra[s].y; cs.z += ra[s].z; cs.w += ra[s].w; }            \
+        }                                                                                                 \
         _Pragma("unroll") for (int s = 0; s < B_IT; ++s)                                                  \
             *reinterpret_cast<float4*>(Bs + (buf_) * BK * BN + (b_r + s * B_RPP) * BN + b_c) = rb[s];     \
     }
@@ -186,6 +190,16 @@ __global__ __launch_bounds__(256, 2) void gemm_mc_kernel(const MCParams p) {
 #undef MC_LOAD
 #undef MC_STORE
 
+    if (do_cs) {       // the A_RPP threads that share a column group add up through LDS (free after the last barrier)
+        *reinterpret_cast<float4*>(smem + a_r * BM + a_c) = cs;
+        __syncthreads();
+        for (int c = tid; c < BM; c += 256) {
+            float t = 0.f;
+#pragma unroll
+            for (int r = 0; r < A_RPP; ++r) t += smem[r * BM + c];
+            if (ti * BM + c < p.Mi) p.colsum[(size_t)split * p.Mi + ti * BM + c] = t;
+        }
+    }
     float* out = p.slab + (size_t)split * p.Mi * p.Nj;
     const int col0 = tj * BN + wn * WN + (lane & 31);
     const int row0 = ti * BM + wm * WM + 4 * (lane >> 5);
@@ -280,12 +294,14 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* __restri
 }
 
 int launch_mc(const float* A, long long lda, int Mi, const float* B, long long ldb, int Nj, int Mk,
-                     bool im2col, int H, int W, int Cin, float* slab, const MCPlan& pl, int engine, hipStream_t st) {
+                     bool im2col, int H, int W, int Cin, float* slab, const MCPlan& pl, int engine, hipStream_t st,
+                     float* colsum) {
     if ((Mi & 3) || (Nj & 3) || (lda & 3) || (ldb & 3)) return PA2D_ERR_ARG;
     if (im2col && (Cin & 3)) return PA2D_ERR_UNSUPPORTED;
     MCParams p;
     p.A = A; p.lda = lda; p.Mi = Mi; p.B = B; p.ldb = ldb; p.Nj = Nj; p.slab = slab; p.Mk = Mk;
     p.chunks_per_split = pl.chunks_per_split; p.splits = pl.splits; p.H = H; p.W = W; p.Cin = Cin;
+    p.colsum = colsum;
     {
         const unsigned long long ab = ((unsigned long long)(Mk - 1) * lda + Mi) * 4ull;
         const unsigned long long bb = ((unsigned long long)(Mk - 1) * ldb + (im2col ? Cin : Nj)) * 4ull;
