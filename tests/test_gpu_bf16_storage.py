@@ -49,7 +49,8 @@ def test_layernorm_bf16(rows, C):
     assert rel_l2(dg, gd.grad) < 1e-4 and rel_l2(db, bd.grad) < 1e-4          # fp32 reductions of exact inputs
 
 
-@pytest.mark.parametrize("M,N,K,act", [(60, 32, 32, "gelu"), (4096, 256, 256, "gelu"), (1000, 512, 64, None), (333, 96, 160, "silu")])
+@pytest.mark.parametrize("M,N,K,act", [(60, 32, 32, "gelu"), (4096, 256, 256, "gelu"), (1000, 512, 64, None), (333, 96, 160, "silu"),
+                                       (66001, 256, 256, "gelu"), (65536, 192, 128, None)])      # last two: row-panel kernel
 def test_linear_bf16(M, N, K, act):
     from transformerbasednavierstokesolver_amd import ops
     from oracle import transolver_oracle as orc

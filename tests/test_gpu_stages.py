@@ -50,6 +50,14 @@ def test_linear(dev, M, N, K, act, engine):
     _check_linear(dev, M, N, K, act, engine, FWD_TOL, BWD_TOL)
 
 
+# large-M linears of the split engine run on the persistent row-panel kernel (>= 256 tiles of 256 x 128): residual
+# preloaded into the accumulators, GELU / GELU' fast epilogues, ragged last row block and ragged columns, generic epilogue
+@pytest.mark.parametrize("M,N,K,act", [(70000, 256, 256, "gelu"), (65536, 256, 256, None), (66001, 192, 128, None),
+                                       (65553, 128, 512, "silu")])
+def test_linear_row_panel(dev, M, N, K, act):
+    _check_linear(dev, M, N, K, act, "split", FWD_TOL, BWD_TOL)
+
+
 def _check_linear(dev, M, N, K, act, engine, FWD_TOL, BWD_TOL):
     from transformerbasednavierstokesolver_amd import ops
     from oracle import transolver_oracle as orc
@@ -241,6 +249,7 @@ def _bf16_stage_cases(dev):
         _check_conv(dev, *args, "bf16", 1e-2, 1e-2)
     _check_linear(dev, 4096, 256, 256, "gelu", "bf16", 1e-2, 1e-2)
     _check_linear(dev, 1000, 512, 76, None, "bf16", 1e-2, 1e-2)
+    _check_linear(dev, 66001, 256, 256, "gelu", "bf16", 1e-2, 1e-2)        # row-panel kernel, one bf16 term, ragged tail
 
 
 def test_small_parameter_gradients_accumulate_in_place(dev):

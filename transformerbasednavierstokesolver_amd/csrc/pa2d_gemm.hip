@@ -27,9 +27,10 @@ KCTile kc_tile(int M, int N, bool im2col, int Cin) {
     if (t12864 >= 384 || M <= 64) return {128, 64, bk};
     return {64, 64, bk};
 }
-// (the split engine serves the conv implicit GEMMs only.  Measured round 2: the K = C linears as 6-term splits with
-// operands converted while staging run at the SAME 0.155 ms as on the exact engine — they are bound by their short
-// K loop (8 K-steps between a cold prologue and a 128 KB epilogue), not by the matrix pipe.)
+// (per-TILE kernels: the split engine serves the conv implicit GEMMs only.  Measured round 2: the K = C linears as
+// 6-term splits on 128x128 tiles run at the SAME 0.155 ms as on the exact engine — they are bound by their short K loop
+// (8 K-steps between a cold prologue and an epilogue), not by the matrix pipe.  Large-M linears of the bf16 engines
+// therefore take the persistent row-panel kernel instead, see panel_applies / pa2d_gemm_panel.hip.)
 bool use_split(int engine, int N, bool im2col, int Cin) {
     const int m = engine;
     if (m == 1) return im2col && N > 64 && (Cin % 32) == 0;
@@ -37,7 +38,8 @@ bool use_split(int engine, int N, bool im2col, int Cin) {
     return false;
 }
 
-static int launch_kc(const KCParams& p_in, bool im2col, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr) {
+static int launch_kc(const KCParams& p_in, bool im2col, hipStream_t st, hipEvent_t ev0 = nullptr, hipEvent_t ev1 = nullptr);
+static int launch_kc(const KCParams& p_in, bool im2col, hipStream_t st, hipEvent_t ev0, hipEvent_t ev1) {
     KCParams p = p_in;
     if (!engine_ok(p.engine)) return PA2D_ERR_ARG;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return PA2D_OK;
@@ -60,7 +62,22 @@ static int launch_kc(const KCParams& p_in, bool im2col, hipStream_t st, hipEvent
     if (im2col && (p.epi != 0 || p.res)) return PA2D_ERR_ARG;      // conv kernels carry the bias-only epilogue
     if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return PA2D_ERR_ARG;
     int rc;
-    if (p.io_bf16 || use_split(p.engine, p.N, im2col, p.Cin)) rc = launch_kc_split(p, im2col, st);
+    if (panel_applies(p, im2col)) {
+        // persistent row-panel kernel on the whole 256-row blocks, the per-tile kernels on the (< 256-row) tail
+        KCParams pp = p;
+        pp.M = p.M - p.M % 256;
+        rc = launch_kc_panel(pp, st);
+        if (!rc && pp.M < p.M) {
+            KCParams pt = p_in;
+            const size_t ea = p.io_bf16 ? 2 : 4, es = p.io_bf16 ? 2 : 4;
+            pt.M = p.M - pp.M;
+            pt.A = (const float*)((const char*)p.A + (size_t)pp.M * p.lda * ea);
+            pt.C = (float*)((char*)p.C + (size_t)pp.M * p.ldc * es);
+            if (p.res) pt.res = (const float*)((const char*)p.res + (size_t)pp.M * p.ldres * es);
+            if (p.aux) pt.aux = (float*)((char*)p.aux + (size_t)pp.M * p.ldaux * es);
+            rc = launch_kc(pt, false, st);
+        }
+    } else if (p.io_bf16 || use_split(p.engine, p.N, im2col, p.Cin)) rc = launch_kc_split(p, im2col, st);
     else rc = launch_kc_f32(p, im2col, kc_tile(p.M, p.N, im2col, p.Cin), st);
     if (rc) return rc;
     if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return PA2D_ERR_ARG;

@@ -134,6 +134,9 @@ int launch_kc_split(KCParams& p, bool im2col, hipStream_t st);
 size_t planes_bytes(long long rows, int C, int NT);
 int launch_split_planes(const float* src, long long ld, void* dst, long long rows, int C, int NT, hipStream_t st);
 int launch_repack_split(const float* w0, const float* w1, void* dst, int bwd, int NT, int C, int Cin, hipStream_t st);
+// persistent row-panel kernel for large-M plain GEMMs of the bf16 engines (pa2d_gemm_panel.hip)
+bool panel_applies(const KCParams& p, bool im2col);
+int launch_kc_panel(const KCParams& p, hipStream_t st);
 // conv with the halo tile resident in LDS (pa2d_conv_halo.hip): used by launch_kc_split for pre-split im2col operands
 bool conv_halo_applies(const KCParams& p);
 int launch_conv_halo(const KCParams& p, hipStream_t st);
