@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_planes_kernel(const float* 
 }
 
 // dx = rstd * (g*dy - mean_c(g*dy) - xhat * mean_c(g*dy*xhat)) (+ dres);  partial[blk] = [dg | db]
-template <typename T>
+template <typename T, int NV>
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd,
@@ -130,9 +130,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nvec = C >> 2;
     const float4* g4 = reinterpret_cast<const float4*>(g);
-    float4 gv[LN_MAXV], dga[LN_MAXV], dba[LN_MAXV];
+    float4 gv[NV], dga[NV], dba[NV];
 #pragma unroll
-    for (int k = 0; k < LN_MAXV; ++k) {
+    for (int k = 0; k < NV; ++k) {
         const int i = lane + 64 * k;
         gv[k] = i < nvec ? g4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         dga[k] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -140,17 +140,38 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
     }
     const int r0 = blockIdx.x * rows_per_block;
     const int r1 = min(rows, r0 + rows_per_block);
+    // one wave per row, software-pipelined by one row: the three operand loads of row + 4 are in flight while the wave
+    // reduces and stores row (the kernel is latency-bound otherwise: two dependent load rounds per row)
+    float4 xn_[NV], dn_[NV], rn_[NV];
+    float mun = 0.f, rsn = 0.f;
+#define LNB_LOAD(row_)                                                                            \
+    {                                                                                             \
+        const T* xrow_ = x + (size_t)(row_) * C;                                                  \
+        const T* drow_ = dy + (size_t)(row_) * C;                                                 \
+        _Pragma("unroll") for (int k = 0; k < NV; ++k) {                                     \
+            const int i = lane + 64 * k;                                                          \
+            if (i < nvec) {                                                                       \
+                xn_[k] = Act<T>::ld4(xrow_ + 4 * i);                                              \
+                dn_[k] = Act<T>::ld4(drow_ + 4 * i);                                              \
+                rn_[k] = dres ? Act<T>::ld4(dres + (size_t)(row_) * C + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f); \
+            }                                                                                     \
+        }                                                                                         \
+        mun = mean[row_]; rsn = rstd[row_];                                                       \
+    }
+    if (r0 + wave < r1) LNB_LOAD(r0 + wave)
     for (int row = r0 + wave; row < r1; row += 4) {
-        const T* xrow = x + (size_t)row * C;
-        const T* drow = dy + (size_t)row * C;
-        const float mu = mean[row], rs = rstd[row];
-        float4 xh[LN_MAXV], gd[LN_MAXV];
+        float4 xc[NV], dc[NV], rc_[NV];
+#pragma unroll
+        for (int k = 0; k < NV; ++k) { xc[k] = xn_[k]; dc[k] = dn_[k]; rc_[k] = rn_[k]; }
+        const float mu = mun, rs = rsn;
+        if (row + 4 < r1) LNB_LOAD(row + 4)
+        float4 xh[NV], gd[NV];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int k = 0; k < LN_MAXV; ++k) {
+        for (int k = 0; k < NV; ++k) {
             const int i = lane + 64 * k;
             if (i < nvec) {
-                const float4 xv = Act<T>::ld4(xrow + 4 * i), dv = Act<T>::ld4(drow + 4 * i);
+                const float4 xv = xc[k], dv = dc[k];
                 xh[k] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
                 gd[k] = make_float4(gv[k].x * dv.x, gv[k].y * dv.y, gv[k].z * dv.z, gv[k].w * dv.w);
                 s1 += gd[k].x + gd[k].y + gd[k].z + gd[k].w;
@@ -164,24 +185,21 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
         }
         const float c1 = wave_sum(s1) / C, c2 = wave_sum(s2) / C;
         T* orow = dx + (size_t)row * C;
-        const T* rrow = dres ? dres + (size_t)row * C : nullptr;
 #pragma unroll
-        for (int k = 0; k < LN_MAXV; ++k) {
+        for (int k = 0; k < NV; ++k) {
             const int i = lane + 64 * k;
             if (i < nvec) {
                 float4 o = make_float4(rs * (gd[k].x - c1 - xh[k].x * c2), rs * (gd[k].y - c1 - xh[k].y * c2),
                                        rs * (gd[k].z - c1 - xh[k].z * c2), rs * (gd[k].w - c1 - xh[k].w * c2));
-                if (rrow) {
-                    const float4 rr = Act<T>::ld4(rrow + 4 * i);
-                    o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
-                }
+                o.x += rc_[k].x; o.y += rc_[k].y; o.z += rc_[k].z; o.w += rc_[k].w;
                 Act<T>::st4(orow + 4 * i, o);
             }
         }
     }
+#undef LNB_LOAD
     float4* s4 = reinterpret_cast<float4*>(smem) + (size_t)wave * 2 * nvec;
 #pragma unroll
-    for (int k = 0; k < LN_MAXV; ++k) {
+    for (int k = 0; k < NV; ++k) {
         const int i = lane + 64 * k;
         if (i < nvec) {
             s4[i] = dga[k];
@@ -310,7 +328,9 @@ static int ln_bwd_t(const T* dy, const T* x, const float* mean, const float* rst
     const int nb = row_blocks(rows);
     const int rpb = ceil_div(rows, nb);
     float* part = (float*)ws;
-    hipLaunchKernelGGL((layernorm_bwd_kernel<T>), dim3(nb), dim3(256), sizeof(float) * 8 * C, st, dy, x, mean, rstd, g,
+    // NV = float4 per lane (C <= 256 NV): the common C <= 256 gets the small-register variant
+    auto kern = C <= 256 ? &layernorm_bwd_kernel<T, 1> : (C <= 512 ? &layernorm_bwd_kernel<T, 2> : &layernorm_bwd_kernel<T, LN_MAXV>);
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(256), sizeof(float) * 8 * C, st, dy, x, mean, rstd, g,
                        dres, dx, part, rows, C, rpb);
     PA2D_CHECK_LAUNCH();
     ReduceSegs segs;

@@ -565,22 +565,20 @@ __global__ __launch_bounds__(256) void slice_bwd_kernel(const SliceBwdParams p) 
                 const unsigned ox = ok ? rowb + (unsigned)(((cx >> 5) * PL) * 64 + (cx & 31) * 2) : OOB_OFF;
                 const unsigned of_ = ok ? rowb + (unsigned)(((cf >> 5) * PL) * 64 + (cf & 31) * 2) : OOB_OFF;
                 const float xv[4] = {xo.x, xo.y, xo.z, xo.w}, fv[4] = {fo.x, fo.y, fo.z, fo.w};
-                float xr[4] = {xv[0], xv[1], xv[2], xv[3]}, fr[4] = {fv[0], fv[1], fv[2], fv[3]};
                 typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
+                typedef __bf16 bf16x4_ __attribute__((ext_vector_type(4)));
+                typedef float f32x4_ __attribute__((ext_vector_type(4)));
+                // exact split x = hi + mid + lo with packed conversions (v_cvt_pk_bf16_f32: two values per instruction)
+                f32x4_ xr = {xo.x, xo.y, xo.z, xo.w}, fr = {fo.x, fo.y, fo.z, fo.w};
 #pragma unroll
                 for (int q = 0; q < PL; ++q) {
-                    unsigned short hx[4], hf[4];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        hx[e] = f32_to_bf16_bits(xr[e]);
-                        hf[e] = f32_to_bf16_bits(fr[e]);
-                        xr[e] -= bf16_bits_to_f32(hx[e]);
-                        fr[e] -= bf16_bits_to_f32(hf[e]);
+                    const bf16x4_ hx = __builtin_convertvector(xr, bf16x4_), hf = __builtin_convertvector(fr, bf16x4_);
+                    if (q + 1 < PL) {
+                        xr -= __builtin_convertvector(hx, f32x4_);
+                        fr -= __builtin_convertvector(hf, f32x4_);
                     }
-                    const u32x2_ qx = {(unsigned)hx[0] | ((unsigned)hx[1] << 16), (unsigned)hx[2] | ((unsigned)hx[3] << 16)};
-                    const u32x2_ qf = {(unsigned)hf[0] | ((unsigned)hf[1] << 16), (unsigned)hf[2] | ((unsigned)hf[3] << 16)};
-                    __builtin_amdgcn_raw_buffer_store_b64(qx, rpl, ox == OOB_OFF ? OOB_OFF : ox + q * 64u, 0, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(qf, rpl, of_ == OOB_OFF ? OOB_OFF : of_ + q * 64u, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, hx), rpl, ox == OOB_OFF ? OOB_OFF : ox + q * 64u, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2_, hf), rpl, of_ == OOB_OFF ? OOB_OFF : of_ + q * 64u, 0, 0);
                 }
                 if (ok) {
 #pragma unroll
