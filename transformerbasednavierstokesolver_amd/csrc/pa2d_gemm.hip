@@ -190,7 +190,10 @@ int pa2d_gemm_bwd_weight(const float* dy, long long lddy, const float* x, long l
     const MCPlan pl = plan_mc(N, K, M);
     // the bias gradient (column sums of dy) rides in the GEMM: the workgroups of column tile 0 sum the dy tiles they stage
     float* cs = db ? (float*)ws + pl.slab_floats : nullptr;
-    int rc = launch_mc(dy, lddy, N, x, ldx, K, M, false, 0, 0, 0, (float*)ws, pl, engine, st, cs);
+    // bf16 engines: the same split plan on the transposed-read planes kernel, operands split while staging
+    const bool bfk = (engine == 1 || engine == 2) && pl.big && mc_f32src_applies(N, K, M, lddy, ldx);
+    int rc = bfk ? launch_mc_f32src(dy, lddy, N, x, ldx, K, M, (float*)ws, pl, engine == 2 ? 1 : 3, cs, st)
+                 : launch_mc(dy, lddy, N, x, ldx, K, M, false, 0, 0, 0, (float*)ws, pl, engine, st, cs);
     if (rc) return rc;
     rc = launch_reduce((const float*)ws, pl.splits, (long long)N * K, dw, nullptr, 0, 0, 0, st, accumulate);
     if (rc) return rc;

@@ -159,6 +159,10 @@ int launch_mc_planes_big(const void* PA, const void* PB, int C, int Cin, int Mk,
                          const MCPlan& pl, int NT, hipStream_t st);
 int launch_mc_planes_big_raw(const void* PA, int Mi, const void* PB, int Cin, int taps, int Mk, int H, int W, float* slab,
                              const MCPlan& pl, int NT, hipStream_t st);
+// plain dW of a linear layer straight from fp32 operands on the 128 x 128 planes kernel (split while staging)
+bool mc_f32src_applies(int Mi, int Nj, int Mk, long long lda, long long ldb);
+int launch_mc_f32src(const float* A, long long lda, int Mi, const float* B, long long ldb, int Nj, int Mk, float* slab,
+                     const MCPlan& pl, int NT, float* colsum, hipStream_t st);
 int colsum_blocks(int M);
 int launch_colsum_bf16(const void* X, long long ld, int M, int N, float* out, float* partial, hipStream_t st,
                        float* out2 = nullptr, int split = 0, int accumulate = 0);

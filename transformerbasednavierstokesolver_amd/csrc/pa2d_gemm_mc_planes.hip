@@ -20,6 +20,8 @@ struct MCPlanesParams {
     int Mi, Nj, Mk, chunks_per_split, splits, H, W, Cin;
     unsigned a_bytes, b_bytes;
     int taps;                     // 9: columns are (tap, input channel) of a 3x3 conv; 1: plain dW = A^T . B (big kernel only)
+    long long lda, ldb;           // F32SRC (128 x 128 kernel): PA / PB are fp32 row-major matrices [Mk][lda], [Mk][ldb]
+    float* colsum;                // F32SRC, optional: [splits][Mi] per-split column sums of A (= a linear layer's bias gradient)
 };
 
 __device__ __forceinline__ unsigned img_off(int row, int ch) {       // byte offset inside one 4 KB plane image
@@ -28,7 +30,10 @@ __device__ __forceinline__ unsigned img_off(int row, int ch) {       // byte off
 
 // KS = 16-row K-steps per LDS stage (one barrier per stage): 1 for NT = 3 (24 MFMAs per wave and barrier, 48 KB of LDS),
 // 4 for NT = 1 (16 MFMAs per barrier instead of 4, 64 KB).
-template <int NT, int KS>
+// F32SRC: plain dW = A^T . B of a linear layer straight from the fp32 operands (no tap shift): each thread loads the 8
+// floats of its (row, 8-column piece) of both operands, splits them into the NT bf16 planes in registers and writes the
+// same LDS plane images; the column sums of A (the bias gradient) are accumulated from the registers of column tile 0.
+template <int NT, int KS, bool F32SRC = false>
 __global__ __launch_bounds__(256, 2) void gemm_mc_planes_kernel(const MCPlanesParams p) {
     constexpr int PIMG = 4096;                       // one plane image of one K-step: 16 rows x 256 B
     constexpr int STAGE = 2 * NT * KS * PIMG;        // A planes then B planes, KS sub-images each
@@ -36,7 +41,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mc_planes_kernel(const MCPlanesPa
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tiles_i = p.Mi / 128, tiles_j = p.Nj / 128;
+    const int tiles_i = (p.Mi + 127) / 128, tiles_j = (p.Nj + 127) / 128;
     int tj, ti, split;
     {
         const int tiles = tiles_i * tiles_j;
@@ -81,9 +86,29 @@ __global__ __launch_bounds__(256, 2) void gemm_mc_planes_kernel(const MCPlanesPa
         s_goff[s] = (unsigned)((((op ? cb0 : ca0) + c) * NT + plane) * 64 + piece * 16);
         s_lds[s] = (unsigned)(((op * NT + plane) * KS + (row >> 4)) * PIMG) + img_off(row & 15, c * 4 + piece);
     }
-    u32x4 rg[NP];
+    u32x4 rg[F32SRC ? 4 * KS : NP];
+    // F32SRC staging: thread = (row, 8-column piece) of both operands
+    const int frow = tid >> 4, fc8 = tid & 15;
+    const unsigned flds = img_off(frow, fc8);
+    const bool fok_a = ti * 128 + fc8 * 8 < p.Mi, fok_b = tj * 128 + fc8 * 8 < p.Nj;
+    const unsigned fcol_a = (unsigned)(ti * 128 + fc8 * 8) * 4u, fcol_b = (unsigned)(tj * 128 + fc8 * 8) * 4u;
+    const unsigned fpitch_a = (unsigned)p.lda * 4u, fpitch_b = (unsigned)p.ldb * 4u;
+    float cs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) cs[e] = 0.f;
 #define MP_LOAD(c_)                                                                                       \
-    {                                                                                                     \
+    if constexpr (F32SRC) {                                                                               \
+        _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) {                                               \
+            const int m_ = ((c_) + ks) * 16 + frow;                                                       \
+            const bool okr_ = m_ < p.Mk && (c_) + ks < c_end;                                             \
+            const unsigned oa_ = (okr_ && fok_a) ? (unsigned)m_ * fpitch_a + fcol_a : OOB_OFF;            \
+            const unsigned ob_ = (okr_ && fok_b) ? (unsigned)m_ * fpitch_b + fcol_b : OOB_OFF;            \
+            rg[ks * 4 + 0] = __builtin_amdgcn_raw_buffer_load_b128(ra_rsrc, oa_, 0, 0);                   \
+            rg[ks * 4 + 1] = __builtin_amdgcn_raw_buffer_load_b128(ra_rsrc, oa_ == OOB_OFF ? OOB_OFF : oa_ + 16u, 0, 0); \
+            rg[ks * 4 + 2] = __builtin_amdgcn_raw_buffer_load_b128(rb_rsrc, ob_, 0, 0);                   \
+            rg[ks * 4 + 3] = __builtin_amdgcn_raw_buffer_load_b128(rb_rsrc, ob_ == OOB_OFF ? OOB_OFF : ob_ + 16u, 0, 0); \
+        }                                                                                                 \
+    } else {                                                                                              \
         const int m0_ = (c_) * 16;                                                                        \
         _Pragma("unroll") for (int s = 0; s < NP; ++s) {                                                  \
             const int m_ = m0_ + s_row[s];                                                                \
@@ -101,10 +126,30 @@ __global__ __launch_bounds__(256, 2) void gemm_mc_planes_kernel(const MCPlanesPa
         }                                                                                                 \
     }
 #define MP_STORE(buf_)                                                                                    \
-    {                                                                                                     \
+    if constexpr (F32SRC) {                                                                               \
+        _Pragma("unroll") for (int ks = 0; ks < KS; ++ks) _Pragma("unroll") for (int op = 0; op < 2; ++op) { \
+            const u32x4 u0_ = rg[ks * 4 + op * 2], u1_ = rg[ks * 4 + op * 2 + 1];                         \
+            const float4 v0_ = make_float4(__uint_as_float(u0_.x), __uint_as_float(u0_.y), __uint_as_float(u0_.z), __uint_as_float(u0_.w)); \
+            const float4 v1_ = make_float4(__uint_as_float(u1_.x), __uint_as_float(u1_.y), __uint_as_float(u1_.z), __uint_as_float(u1_.w)); \
+            if (op == 0 && do_cs) {                                                                       \
+                cs[0] += v0_.x; cs[1] += v0_.y; cs[2] += v0_.z; cs[3] += v0_.w;                           \
+                cs[4] += v1_.x; cs[5] += v1_.y; cs[6] += v1_.z; cs[7] += v1_.w;                           \
+            }                                                                                             \
+            bf16x4 h0_, m0_, l0_, h1_, m1_, l1_;                                                          \
+            split3(v0_, h0_, m0_, l0_);                                                                   \
+            split3(v1_, h1_, m1_, l1_);                                                                   \
+            unsigned char* d_ = smem + (buf_) * STAGE + flds;                                             \
+            *reinterpret_cast<bf16x8*>(d_ + ((op * NT + 0) * KS + ks) * PIMG) = __builtin_shufflevector(h0_, h1_, 0, 1, 2, 3, 4, 5, 6, 7); \
+            if (NT == 3) {                                                                                \
+                *reinterpret_cast<bf16x8*>(d_ + ((op * NT + 1) * KS + ks) * PIMG) = __builtin_shufflevector(m0_, m1_, 0, 1, 2, 3, 4, 5, 6, 7); \
+                *reinterpret_cast<bf16x8*>(d_ + ((op * NT + 2) * KS + ks) * PIMG) = __builtin_shufflevector(l0_, l1_, 0, 1, 2, 3, 4, 5, 6, 7); \
+            }                                                                                             \
+        }                                                                                                 \
+    } else {                                                                                              \
         _Pragma("unroll") for (int s = 0; s < NP; ++s)                                                    \
             *reinterpret_cast<u32x4*>(smem + (buf_) * STAGE + s_lds[s]) = rg[s];                          \
     }
+    const bool do_cs = F32SRC && p.colsum != nullptr && tj == 0;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -175,6 +220,20 @@ __global__ __launch_bounds__(256, 2) void gemm_mc_planes_kernel(const MCPlanesPa
 #undef MP_LOAD
 #undef MP_STORE
 
+    if constexpr (F32SRC) {
+        if (do_cs) {       // the 16 row-threads of a column piece add up through LDS (free after the last barrier)
+            float* sm = reinterpret_cast<float*>(smem);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sm[frow * 128 + fc8 * 8 + e] = cs[e];
+            __syncthreads();
+            if (tid < 128) {
+                float t = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += sm[r * 128 + tid];
+                if (ti * 128 + tid < p.Mi) p.colsum[(size_t)split * p.Mi + ti * 128 + tid] = t;
+            }
+        }
+    }
     float* out = p.slab + (size_t)split * p.Mi * p.Nj;
     const int col0 = tj * 128 + wn * 64 + (lane & 31);
     const int row0 = ti * 128 + wm * 64 + 4 * (lane >> 5);
@@ -185,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mc_planes_kernel(const MCPlanesPa
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
-                out[(size_t)row * p.Nj + col0 + j * 32] = acc[i][j][r];
+                if (!F32SRC || (row < p.Mi && col0 + j * 32 < p.Nj)) out[(size_t)row * p.Nj + col0 + j * 32] = acc[i][j][r];
             }
 }
 
@@ -445,6 +504,31 @@ int launch_mc_planes_big_raw(const void* PA, int Mi, const void* PB, int Cin, in
         }
         hipLaunchKernelGGL((gemm_mc_planes_big_kernel<1, 4>), grid, dim3(512), smem, st, p, per_xcd);
     }
+    PA2D_CHECK_LAUNCH();
+    return PA2D_OK;
+}
+
+// Plain dW = A^T . B of the bf16 engines straight from fp32 operands (A [Mk][lda] with Mi columns, B [Mk][ldb] with Nj
+// columns; Mi, Nj multiples of 8), 128 x 128 tiles on plan_mc's split plan; colsum (optional): [splits][Mi].
+bool mc_f32src_applies(int Mi, int Nj, int Mk, long long lda, long long ldb) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("PA2D_LIN_DW_SPLIT"); on = (e && e[0] == 'o' && e[1] == 'f') ? 0 : 1; }
+    return on && (Mi % 8) == 0 && (Nj % 8) == 0 && Mi > 64 && Nj > 64 && Mk >= 16 * 8 * 16 && (lda % 4) == 0 && (ldb % 4) == 0;
+}
+
+int launch_mc_f32src(const float* A, long long lda, int Mi, const float* B, long long ldb, int Nj, int Mk, float* slab,
+                     const MCPlan& pl, int NT, float* colsum, hipStream_t st) {
+    if (!pl.big) return PA2D_ERR_UNSUPPORTED;
+    MCPlanesParams p = {};
+    p.PA = A; p.PB = B; p.slab = slab; p.lda = lda; p.ldb = ldb; p.colsum = colsum;
+    p.Mi = Mi; p.Nj = Nj; p.Mk = Mk; p.chunks_per_split = pl.chunks_per_split; p.splits = pl.splits;
+    p.H = 1; p.W = 1; p.Cin = Nj; p.taps = 1; p.chA = 0; p.chB = 0;
+    const unsigned long long ab = ((unsigned long long)(Mk - 1) * lda + Mi) * 4ull, bb = ((unsigned long long)(Mk - 1) * ldb + Nj) * 4ull;
+    if (ab >= 0xFFFFFFF0ull || bb >= 0xFFFFFFF0ull) return PA2D_ERR_UNSUPPORTED;
+    p.a_bytes = (unsigned)ab; p.b_bytes = (unsigned)bb;
+    const dim3 grid(ceil_div(Mi, 128) * ceil_div(Nj, 128) * pl.splits);
+    if (NT == 3) hipLaunchKernelGGL((gemm_mc_planes_kernel<3, 1, true>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((gemm_mc_planes_kernel<1, 4, true>), grid, dim3(256), 0, st, p);
     PA2D_CHECK_LAUNCH();
     return PA2D_OK;
 }
