@@ -53,7 +53,8 @@ CONV_KERNELS = {ops.ENGINE_F32: ("gemm_kc_kernel<128,128,2,2,true,32>", PEAK_FP3
                 ops.ENGINE_BF16: ("conv_halo_kernel<1>", PEAK_BF16_MFMA_TFLOPS),
                 ops.ENGINE_BF16S: ("conv_halo_kernel<1,bf16>", PEAK_BF16_MFMA_TFLOPS)}
 ENGINE_LABEL = {ops.ENGINE_F32: "exact fp32 MFMA (all GEMMs)",
-                ops.ENGINE_SPLIT: "3xbf16-split/fp32-acc (conv), exact fp32 MFMA (linears)",
+                ops.ENGINE_SPLIT: "3xbf16-split/fp32-acc (conv and large-M linear GEMMs, forward / data / weight "
+                                  "gradients); exact fp32 MFMA for the small GEMMs",
                 ops.ENGINE_BF16: "bf16 MFMA compute, f32 accumulate+storage (all GEMMs)",
                 ops.ENGINE_BF16S: "bf16 storage (activations, saved tensors, inter-kernel gradients) + bf16 MFMA, f32 "
                                   "accumulate / master weights / statistics"}

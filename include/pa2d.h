@@ -42,9 +42,11 @@ const char* pa2d_version(void);
 
 /* GEMM engines (the `engine` argument of the dense entry points):
  * PA2D_ENGINE_F32   exact fp32 MFMA (v_mfma_f32_32x32x2_f32);
- * PA2D_ENGINE_SPLIT fp32-accurate split (conv GEMMs: forward, data and weight gradients): operands split exactly
- *                   into 3 bf16 terms, 6 bf16 MFMA terms per product, fp32 accumulate — same parity tolerances as
- *                   the exact engine; every other GEMM stays exact;
+ * PA2D_ENGINE_SPLIT fp32-accurate split: operands split exactly into 3 bf16 terms, 6 bf16 MFMA terms per product, fp32
+ *                   accumulate — same parity tolerances as the exact engine.  Used by the conv GEMMs
+ *                   (forward, data and weight gradients) and by the large-M plain GEMMs (K % 32 == 0, >= 256 tiles of
+ *                   256 x 128 rows x columns: forward / data gradient; weight gradient from 2048 rows); small GEMMs
+ *                   stay on the exact kernels;
  * PA2D_ENGINE_BF16  bf16 compute: every GEMM rounds its operands to bf16 and uses ONE bf16 MFMA term with fp32
  *                   accumulation; tensors stay fp32 in HBM (autocast-style numerics, tolerance rel-L2 <= 3e-2).
  * Workspace sizes and weight-pack layouts depend on the engine: query them, and make packs, with the engine used.

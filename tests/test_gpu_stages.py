@@ -338,6 +338,45 @@ def test_split_engine_adversarial_operands(dev):
     assert int(bad[0].sum()) == 9 and int(bad[1].sum()) == 18            # exactly the three 3x3 windows
 
 
+def test_split_engine_adversarial_operands_linear(dev):
+    """The same conditions on the large-M plain GEMMs, which the split engine also serves (row-panel forward / data
+    gradient kernel, transposed-read weight-gradient kernel): per-row dynamic range 2^+-40, everything at 2^-90, zero rows,
+    +-inf / NaN rows.  Asserted: split error <= 2 x exact error + 1e-7 against fp64, zero rows give exactly the bias, the
+    non-finite outputs coincide (whole rows of the poisoned elements, nothing else)."""
+    from transformerbasednavierstokesolver_amd import ops
+    M, N, K = 65536, 256, 256
+    rng = np.random.default_rng(7)
+    w, b = _r(rng, N, K, scale=K ** -0.5), 0.1 * _r(rng, N)
+    base, dy = _r(rng, M, K), _r(rng, M, N)
+    g = lambda t: t.to(dev)
+    scale = torch.from_numpy(np.exp2(rng.uniform(-40, 40, size=(M, 1))).astype(np.float32))
+    zb = torch.zeros(N)
+    for name, x, bias in (("range 2^+-40", base * scale, b), ("all at 2^-90", base * 2.0 ** -90, zb)):
+        r = x.double() @ w.double().t() + bias.double()
+        rw = dy.double().t() @ x.double()
+        errs, errw = {}, {}
+        for e in ("f32", "split"):
+            out = ops.linear_fwd(g(x), g(w), g(bias), engine=e)[0].double().cpu()
+            errs[e] = float(((out - r) * 2.0 ** 80).norm() / (r * 2.0 ** 80).norm())
+            dw, _ = ops.linear_bwd_weight(g(dy), g(x), engine=e)
+            errw[e] = float(((dw.double().cpu() - rw) * 2.0 ** 60).norm() / (rw * 2.0 ** 60).norm())
+        assert errs["split"] <= 2 * errs["f32"] + 1e-7 and errs["f32"] < 1e-5, (name, errs)
+        assert errw["split"] <= 2 * errw["f32"] + 1e-7 and errw["f32"] < 1e-5, (name, errw)
+    xz = base.clone()
+    xz[1000:3000] = 0.0
+    for e in ("f32", "split"):
+        out = ops.linear_fwd(g(xz), g(w), g(b), engine=e)[0].cpu()
+        assert torch.equal(out[1000:3000], b.expand(2000, N)), e
+    xp = base.clone()
+    xp[5, 3] = float("inf")
+    xp[40000, 0] = float("nan")
+    xp[65535, 255] = -float("inf")
+    masks = {e: torch.isfinite(ops.linear_fwd(g(xp), g(w), g(b), engine=e)[0]).cpu() for e in ("f32", "split")}
+    assert torch.equal(masks["f32"], masks["split"])
+    bad = (~masks["split"]).any(-1)
+    assert bad.nonzero().flatten().tolist() == [5, 40000, 65535] and bool((~masks["split"])[5].all())
+
+
 def _unplane(planes, rows, C, nt):
     """fp64 tensor [rows, C] held by a plane image [row][C/32][nt][32] bf16 (sum of the planes)"""
     p = planes.view(torch.bfloat16).view(rows, C // 32, nt, 32).double().sum(2)

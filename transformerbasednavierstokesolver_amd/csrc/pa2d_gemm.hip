@@ -4,7 +4,7 @@
 
 // Engines (explicit `engine` argument of every dense entry point; the library keeps NO engine state, so two
 // models in one process can use different engines): 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = 6-term bf16
-// split at fp32 accuracy (conv GEMMs; other GEMMs stay exact), 2 = bf16 compute for every GEMM (fp32 accumulate
+// split at fp32 accuracy (conv GEMMs and large-M plain GEMMs; small GEMMs stay exact), 2 = bf16 compute for every GEMM (fp32 accumulate
 // and storage).  pa2d_default_engine() only reads the environment (PA2D_GEMM=f32|split|bf16), default = split.
 static bool engine_ok(int e) { return e >= 0 && e <= 2; }
 // K-step: 32 (half the barriers of 16, full 128-byte row segments; 3-4 % faster on the conv, ~10 % on the small tiles)
