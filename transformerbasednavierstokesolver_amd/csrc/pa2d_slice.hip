@@ -777,11 +777,11 @@ int pa2d_slice_nchunk(int B, int N, int heads) {
 static int ppc_for(int N, int nchunk) { return ceil_div(ceil_div(N, nchunk), 16) * 16; }
 // bf16-MFMA forms of the forward kernels (pa2d_slice_bf.hip): the default; PA2D_SLICE_MFMA=f32 keeps the exact-fp32-MFMA
 // kernels of this file (A/B timing, and the reference the new ones are tested against)
-int pa2d_launch_scatter_bf(const void* xm, long long ldx, const void* v, long long ldv, const float* ws, const float* bs,
+__attribute__((visibility("hidden"))) int pa2d_launch_scatter_bf(const void* xm, long long ldx, const void* v, long long ldv, const float* ws, const float* bs,
                            const float* temperature, float* spart, float* npart, int B, int N, int heads, int D, int M,
                            int mt, int nchunk, int ppc, unsigned x_bytes, unsigned v_bytes, int clamp, int xcd_map, bool bf,
                            hipStream_t st);
-int pa2d_launch_deslice_bf(const void* xm, long long ldx, const float* o, const float* ws, const float* bs,
+__attribute__((visibility("hidden"))) int pa2d_launch_deslice_bf(const void* xm, long long ldx, const float* o, const float* ws, const float* bs,
                            const float* temperature, void* y, long long ldy, int B, int N, int heads, int D, int M, int mt,
                            int nchunk, int ppc, unsigned x_bytes, unsigned y_bytes, int clamp, int xcd_map, bool bf, hipStream_t st);
 static int slice_xcd_map() {          // PA2D_SLICE_MAP=legacy keeps the chunk-fastest numbering (A/B timing)

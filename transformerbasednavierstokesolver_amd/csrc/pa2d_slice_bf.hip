@@ -454,7 +454,7 @@ __global__ __launch_bounds__(256) void deslice_bf_kernel(const BfDesliceParams p
     }
 
 // called by pa2d_slice.hip (from inside its extern "C" block) with the fields of its own parameter structs
-extern "C" int pa2d_launch_scatter_bf(const void* xm, long long ldx, const void* v, long long ldv, const float* ws, const float* bs,
+extern "C" __attribute__((visibility("hidden"))) int pa2d_launch_scatter_bf(const void* xm, long long ldx, const void* v, long long ldv, const float* ws, const float* bs,
                            const float* temperature, float* spart, float* npart, int B, int N, int heads, int D, int M,
                            int mt, int nchunk, int ppc, unsigned x_bytes, unsigned v_bytes, int clamp, int xcd_map, bool bf,
                            hipStream_t st) {
@@ -470,7 +470,7 @@ extern "C" int pa2d_launch_scatter_bf(const void* xm, long long ldx, const void*
     return PA2D_OK;
 }
 
-extern "C" int pa2d_launch_deslice_bf(const void* xm, long long ldx, const float* o, const float* ws, const float* bs,
+extern "C" __attribute__((visibility("hidden"))) int pa2d_launch_deslice_bf(const void* xm, long long ldx, const float* o, const float* ws, const float* bs,
                            const float* temperature, void* y, long long ldy, int B, int N, int heads, int D, int M, int mt,
                            int nchunk, int ppc, unsigned x_bytes, unsigned y_bytes, int clamp, int xcd_map, bool bf, hipStream_t st) {
     BfDesliceParams p;
