@@ -347,29 +347,36 @@ int pa2d_launch_reduce(const float* slab, int nslab, long long count, float* out
     return launch_reduce(slab, nslab, count, out, nullptr, 0, 0, 0, st);
 }
 
-// small records (LayerNorm / head / slice / token parameter gradients): one thread per record element, all slabs
-// summed in a fixed order, result routed to its destination segment
+// small records (LayerNorm / head / slice / token parameter gradients): all slabs of a record element summed in a fixed
+// order, result routed to its destination segment.  These reductions are latency-bound (a few MB spread over up to 1024
+// slabs), so the 256 threads of a workgroup are IDX record elements x SL slab lanes with SL chosen by the slab count:
+// every lane walks nslab / SL slabs four loads at a time (1024 slabs: 4 rounds instead of 64), then the SL lane sums
+// are added in lane order.  Deterministic for a given nslab.
+template <int SL>
 __global__ __launch_bounds__(256) void reduce_segs_kernel(const float* __restrict__ slab, int nslab, long long count,
                                                           const ReduceSegs segs, int accumulate) {
-    __shared__ float red[4][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const long long idx = (long long)blockIdx.x * 64 + tx;
+    constexpr int IDX = 256 / SL;
+    __shared__ float red[SL][IDX];
+    const int tx = threadIdx.x % IDX, ty = threadIdx.x / IDX;
+    const long long idx = (long long)blockIdx.x * IDX + tx;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
     if (idx < count) {
         const float* p = slab + idx;
         int k = ty;
-        for (; k + 12 < nslab; k += 16) {
+        for (; k + 3 * SL < nslab; k += 4 * SL) {
             s0 += p[(size_t)k * count];
-            s1 += p[(size_t)(k + 4) * count];
-            s2 += p[(size_t)(k + 8) * count];
-            s3 += p[(size_t)(k + 12) * count];
+            s1 += p[(size_t)(k + SL) * count];
+            s2 += p[(size_t)(k + 2 * SL) * count];
+            s3 += p[(size_t)(k + 3 * SL) * count];
         }
-        for (; k < nslab; k += 4) s0 += p[(size_t)k * count];
+        for (; k < nslab; k += SL) s0 += p[(size_t)k * count];
     }
     red[ty][tx] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (ty != 0 || idx >= count) return;
-    const float s = ((red[0][tx] + red[1][tx]) + red[2][tx]) + red[3][tx];
+    float s = red[0][tx];
+#pragma unroll
+    for (int l = 1; l < SL; ++l) s += red[l][tx];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
         if (i < segs.nseg && idx >= segs.begin[i] && idx < segs.begin[i + 1]) {
@@ -381,8 +388,15 @@ __global__ __launch_bounds__(256) void reduce_segs_kernel(const float* __restric
 int pa2d_launch_reduce_segs(const float* slab, int nslab, long long count, const ReduceSegs& segs, int accumulate,
                             hipStream_t st) {
     if (count <= 0) return PA2D_OK;
-    hipLaunchKernelGGL(reduce_segs_kernel, dim3((unsigned)ceil_div_ll(count, 64)), dim3(256), 0, st, slab, nslab, count,
-                       segs, accumulate);
+    if (nslab >= 256)
+        hipLaunchKernelGGL(reduce_segs_kernel<64>, dim3((unsigned)ceil_div_ll(count, 4)), dim3(256), 0, st, slab, nslab, count,
+                           segs, accumulate);
+    else if (nslab >= 32)
+        hipLaunchKernelGGL(reduce_segs_kernel<16>, dim3((unsigned)ceil_div_ll(count, 16)), dim3(256), 0, st, slab, nslab, count,
+                           segs, accumulate);
+    else
+        hipLaunchKernelGGL(reduce_segs_kernel<4>, dim3((unsigned)ceil_div_ll(count, 64)), dim3(256), 0, st, slab, nslab, count,
+                           segs, accumulate);
     PA2D_CHECK_LAUNCH();
     return PA2D_OK;
 }
