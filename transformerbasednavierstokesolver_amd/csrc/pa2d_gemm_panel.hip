@@ -16,7 +16,8 @@
 // Phase ablation at B*N = 131072, N = K = 256, NT = 3 (ms): full 0.116; MFMAs alone 0.079 (0.056 + 0.023 epilogue =
 // the HBM write of C); loads + convert alone 0.062; loads alone 0.046; nothing but barriers and the epilogue 0.023.
 // The producers' VALU conversion and the consumers' MFMAs add up instead of overlapping (same finding as on the conv),
-// which is what the plane-image operands remove on the conv path.
+// which is what the plane-image operands remove on the conv path.  Starting every second pair of workgroups 3-12 us late
+// (so that their epilogue writes fall into the other half's K loops) measured neutral.
 #include "pa2d_gemm_common.h"
 
 namespace {

@@ -670,31 +670,45 @@ __global__ __launch_bounds__(256) void slice_bwd_kernel(const SliceBwdParams p) 
 }
 
 // dtemperature[h] = mask(0.1 <= t <= 5) * sum over (b, chunk) of the per-block dtau partials
-__global__ void dtau_finalize_kernel(const float* __restrict__ part, const float* __restrict__ temperature,
+// both finalize passes sum B*nchunk per-workgroup records per output: latency-bound, so the records are spread over the
+// lanes (fixed lane -> record assignment and a fixed reduction tree: deterministic)
+__global__ __launch_bounds__(64) void dtau_finalize_kernel(const float* __restrict__ part, const float* __restrict__ temperature,
                                      float* __restrict__ dtemp, int B, int heads, int nchunk, int stride, int off,
                                      int clamp, int accumulate) {
-    const int hh = blockIdx.x * blockDim.x + threadIdx.x;
-    if (hh >= heads) return;
+    const int hh = blockIdx.x, lane = threadIdx.x;      // one wave per head
     float s = 0.f;
-    for (int b = 0; b < B; ++b)
-        for (int c = 0; c < nchunk; ++c) s += part[(size_t)((b * heads + hh) * nchunk + c) * stride + off];
+    for (int r = lane; r < B * nchunk; r += 64) {
+        const int b = r / nchunk, c = r - b * nchunk;
+        s += part[(size_t)((b * heads + hh) * nchunk + c) * stride + off];
+    }
+    s = wave_sum(s);
+    if (lane != 0) return;
     const float t = temperature[hh];
     const float v = (!clamp || (t >= 0.1f && t <= 5.0f)) ? s : 0.f;
     dtemp[hh] = accumulate ? dtemp[hh] + v : v;
 }
-
-// conv bias gradients from the block records of the planes variant: dbx[h*D+d] (+)= sum over (b, chunk) of record[off + d],
-// dbf likewise at off + D
-__global__ void conv_bias_finalize_kernel(const float* __restrict__ part, float* __restrict__ dbx, float* __restrict__ dbf,
-                                          int B, int heads, int nchunk, int stride, int off, int D, int accumulate) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= 2 * heads * D) return;
-    const int which = idx / (heads * D), c = idx - which * heads * D, hh = c / D, d = c - hh * D;
+__global__ __launch_bounds__(256) void conv_bias_finalize_kernel(const float* __restrict__ part, float* __restrict__ dbx,
+                                          float* __restrict__ dbf, int B, int heads, int nchunk, int stride, int off,
+                                          int D, int accumulate) {
+    __shared__ float red[16][16];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;      // 16 outputs x 16 record lanes
+    const int idx = blockIdx.x * 16 + tx;
+    const bool ok = idx < 2 * heads * D;
+    const int which = ok ? idx / (heads * D) : 0, c = idx - which * heads * D, hh = ok ? c / D : 0, d = c - hh * D;
     float s = 0.f;
-    for (int b = 0; b < B; ++b)
-        for (int ch = 0; ch < nchunk; ++ch) s += part[(size_t)((b * heads + hh) * nchunk + ch) * stride + off + which * D + d];
+    if (ok)
+        for (int r = ty; r < B * nchunk; r += 16) {
+            const int b = r / nchunk, ch = r - b * nchunk;
+            s += part[(size_t)((b * heads + hh) * nchunk + ch) * stride + off + which * D + d];
+        }
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty != 0 || !ok) return;
+    float t = red[0][tx];
+#pragma unroll
+    for (int l = 1; l < 16; ++l) t += red[l][tx];
     float* dst = which ? dbf : dbx;
-    dst[c] = accumulate ? dst[c] + s : s;
+    dst[c] = accumulate ? dst[c] + t : t;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -929,11 +943,11 @@ static int slice_bwd_impl(const void* xm, long long ldx, const void* fm, long lo
     segs.dst[0] = dws; segs.dst[1] = dbs; segs.dst[2] = segs.dst[3] = nullptr;
     rc = pa2d_launch_reduce_segs(p.part, grid, stride, segs, accumulate, st);
     if (rc) return rc;
-    hipLaunchKernelGGL(dtau_finalize_kernel, dim3(ceil_div(heads, 64)), dim3(64), 0, st, p.part, temperature,
+    hipLaunchKernelGGL(dtau_finalize_kernel, dim3(heads), dim3(64), 0, st, p.part, temperature,
                        dtemperature, B, heads, p.nchunk, stride, M * D + M, clamp_temperature, accumulate);
     PA2D_CHECK_LAUNCH();
     if (planes && dbx && dbf) {
-        hipLaunchKernelGGL(conv_bias_finalize_kernel, dim3(ceil_div(2 * heads * D, 256)), dim3(256), 0, st, p.part, dbx, dbf, B,
+        hipLaunchKernelGGL(conv_bias_finalize_kernel, dim3(ceil_div(2 * heads * D, 16)), dim3(256), 0, st, p.part, dbx, dbf, B,
                            heads, p.nchunk, stride, M * D + M + 1, D, accumulate);
         PA2D_CHECK_LAUNCH();
     }
