@@ -58,8 +58,11 @@ ENGINE_LABEL = {ops.ENGINE_F32: "exact fp32 MFMA (all GEMMs)",
                 ops.ENGINE_BF16: "bf16 MFMA compute, f32 accumulate+storage (all GEMMs)",
                 ops.ENGINE_BF16S: "bf16 storage (activations, saved tensors, inter-kernel gradients) + bf16 MFMA, f32 "
                                   "accumulate / master weights / statistics"}
-# algorithmic HBM bytes per launch of the slice-path kernels, in units of R*C*4 bytes (R = B*N rows):
-# scatter reads x_mid + v; de-slice reads x_mid, writes y; slice backward reads x_mid, fx_mid, dY, writes dX, dF
+# algorithmic HBM bytes per launch of the slice-path kernels, in units of R*C*e bytes (R = B*N rows, e = bytes per stored
+# activation): scatter reads x_mid + v; de-slice reads x_mid, writes y; slice backward reads x_mid,
+# fx_mid, dY and writes dX, dF — as e-byte tensors (5 units), or, when the engine takes the conv operands as bf16 plane
+# images (ops.conv_planes_mask == 7), as the NT-plane image the conv multiplies: 3 + 2 * NT * 2 / 4 units (split: 6,
+# bf16 compute: 4), which replaces the separate split pass and its traffic
 HBM_KERNELS = {"slice_scatter": ("slice_scatter_kernel", 2.0), "deslice": ("deslice_kernel", 2.0),
                "slice_bwd": ("slice_bwd_kernel", 5.0)}
 
@@ -279,8 +282,9 @@ class Ranks:
             dist.destroy_process_group()
 
 
-def rooflines(ms_by_kind, engine, rows, C, traffic=None):
-    """(roofline, roofline_hbm) dicts from the live HIP-event durations of one workload (rows = B*N)."""
+def rooflines(ms_by_kind, engine, rows, C, traffic=None, planes=False):
+    """(roofline, roofline_hbm) dicts from the live HIP-event durations of one workload (rows = B*N).  planes: the slice
+    backward of this workload emits the conv's plane image (see HBM_KERNELS)."""
     roof = hbm = None
     esize = 2.0 if engine == ops.ENGINE_BF16S else 4.0        # bytes per stored activation element
     conv = ms_by_kind.get("conv") or []
@@ -295,11 +299,14 @@ def rooflines(ms_by_kind, engine, rows, C, traffic=None):
                 "launches_timed": len(conv), "avg_launch_ms": round(avg, 4), "flops_per_launch": flops,
                 "peak_note": ("fp32-equivalent: dense bf16 MFMA peak / 6 terms" if engine == ops.ENGINE_SPLIT else
                               ("dense bf16 MFMA" if engine in (ops.ENGINE_BF16, ops.ENGINE_BF16S) else "fp32 MFMA"))}
+    bwd_units = 3.0 + 2.0 * (3 if engine == ops.ENGINE_SPLIT else 1) * 2.0 / 4.0 if planes else HBM_KERNELS["slice_bwd"][1]
     kernels, tot_b, tot_ms = [], 0.0, 0.0
     for kind, (kname, units) in HBM_KERNELS.items():
         ms = ms_by_kind.get(kind) or []
         if not ms:
             continue
+        if kind == "slice_bwd":
+            units = bwd_units
         nbytes = units * rows * C * esize
         avg = float(np.mean(ms))
         gbs = nbytes / (avg * 1e-3) / 1e9
@@ -312,7 +319,9 @@ def rooflines(ms_by_kind, engine, rows, C, traffic=None):
         hbm = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
                "note": "launch-weighted over the three slice-path kernels; algorithmic bytes per launch = "
-                       f"2 / 2 / 5 x R*C*{int(esize)} B (DESIGN.md §4)", "kernels": kernels}
+                       f"2 / 2 / {bwd_units:g} x R*C*{int(esize)} B (DESIGN.md §4)"
+                       + ("; the slice backward writes dX | dF as the conv's bf16 plane image" if planes else ""),
+               "kernels": kernels}
     return roof, hbm
 
 
@@ -339,7 +348,8 @@ def darcy_leg(rk, pool, engine, batch, steps):
     pool.enabled = True
     dt, (loss, l2, _) = rk.timed(step, steps)
     pool.enabled = False
-    roof, hbm = rooflines(pool.drain_ms(), engine, batch * s * s, cfg["n_hidden"])
+    roof, hbm = rooflines(pool.drain_ms(), engine, batch * s * s, cfg["n_hidden"],
+                          planes=ops.conv_planes_mask(batch, s, s, cfg["n_hidden"], engine) == 7)
     fwd_gflop = 1143.0          # forward GFLOP per sample per call at this geometry
     out = {"workload": f"exp_darcy.py iteration, Darcy 421x421 (N=177241), Transolver_Structured_Mesh_2D 8 layers, "
                        f"C=128, 8 heads, M=128 slices, batch {batch}/GPU (BASELINE configs[4] geometry), "
@@ -451,7 +461,8 @@ def main():
                                      "and launch shape, not measured in this run)"}
         except Exception:
             traffic = None
-    roof, roof_hbm = rooflines(pool.drain_ms(), engine, B * (calls if args.fold_time else 1) * N, C, traffic)
+    roof, roof_hbm = rooflines(pool.drain_ms(), engine, B * (calls if args.fold_time else 1) * N, C, traffic,
+                               planes=ops.conv_planes_mask(B * (calls if args.fold_time else 1), cfg["H"], cfg["W"], C, engine) == 7)
 
     out = {
         "metric": "ns64_train_samples_per_s", "value": round(world * B * args.steps / dt, 4), "unit": "samples/s",
