@@ -299,6 +299,7 @@ def rooflines(ms_by_kind, engine, rows, C, traffic=None, planes=False):
                 "launches_timed": len(conv), "avg_launch_ms": round(avg, 4), "flops_per_launch": flops,
                 "peak_note": ("fp32-equivalent: dense bf16 MFMA peak / 6 terms" if engine == ops.ENGINE_SPLIT else
                               ("dense bf16 MFMA" if engine in (ops.ENGINE_BF16, ops.ENGINE_BF16S) else "fp32 MFMA"))}
+    planes = planes and engine in (ops.ENGINE_SPLIT, ops.ENGINE_BF16)       # bf16 STORAGE writes plain bf16 tensors
     bwd_units = 3.0 + 2.0 * (3 if engine == ops.ENGINE_SPLIT else 1) * 2.0 / 4.0 if planes else HBM_KERNELS["slice_bwd"][1]
     kernels, tot_b, tot_ms = [], 0.0, 0.0
     for kind, (kname, units) in HBM_KERNELS.items():
