@@ -53,7 +53,7 @@ def test_linear(dev, M, N, K, act, engine):
 # large-M linears of the split engine run on the persistent row-panel kernel (>= 256 tiles of 256 x 128): residual
 # preloaded into the accumulators, GELU / GELU' fast epilogues, ragged last row block and ragged columns, generic epilogue
 @pytest.mark.parametrize("M,N,K,act", [(70000, 256, 256, "gelu"), (65536, 256, 256, None), (66001, 192, 128, None),
-                                       (65553, 128, 512, "silu")])
+                                       (65553, 128, 512, "silu"), (65539, 200, 96, None), (65539, 200, 96, "gelu")])
 def test_linear_row_panel(dev, M, N, K, act):
     _check_linear(dev, M, N, K, act, "split", FWD_TOL, BWD_TOL)
 
