@@ -361,7 +361,7 @@ struct SliceBwdParams {
 //   dW = dY.O^T + F.dS^T + dn ; dL = W*(dW - rowsum(dW*W)) ; dF = W.dS ; dX = dL.Ws/tau
 //   dWs += (dL/tau)^T.X ; dbs += sum dL/tau ; dtau -= sum(dL*L)/tau
 template <int D, int MT, typename T, int PL = 0>
-__global__ __launch_bounds__(256) void slice_bwd_kernel(const SliceBwdParams p) {
+__global__ __launch_bounds__(256, (MT <= 4 && D <= 32 && sizeof(T) == 4) ? 2 : 1) void slice_bwd_kernel(const SliceBwdParams p) {
     constexpr int KS = SCfg<D>::KS, DT = SCfg<D>::DT, VEC = SCfg<D>::VEC, NV = SCfg<D>::NV;
     constexpr unsigned ES = Act<T>::ES;
     constexpr int MP = 16 * MT, DP = 16 * DT, P = DP + 4;   // LDS row pitch (floats), 16-B aligned
