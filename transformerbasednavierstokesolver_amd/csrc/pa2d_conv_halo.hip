@@ -210,6 +210,28 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(const KCParams p, con
     // of image row y0 + wm*4 + i, column tile_n*128 + wn*64 + j*32 + (l & 31): 32 lanes write 128 contiguous bytes.
     const __amdgpu_buffer_rsrc_t rc = make_rsrc(p.C, p.c_bytes);
     constexpr unsigned ES = Act<TO>::ES;
+    if (y0 + TH <= p.H && x0 + TW <= p.W) {
+        // tile inside the image (wave-uniform): element = per-lane offset of the wave's first pixel + an SGPR offset per
+        // (image row i, register r); no per-element address arithmetic or bounds tests
+        const unsigned ldc_b = (unsigned)p.ldc * ES, roww_b = (unsigned)p.W * ldc_b;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = tile_n * BN + wn * 64 + j * 32 + (lane & 31);
+            const bool col_ok = col < p.N;
+            const float bv = (p.bias && col_ok) ? (col < p.bias_split ? p.bias[col] : p.bias2[col - p.bias_split]) : 0.f;
+            const unsigned vo = col_ok ? (unsigned)((img * p.H + y0 + wm * 4) * p.W + x0 + 4 * (lane >> 5)) * ldc_b + (unsigned)col * ES
+                                       : OOB_OFF;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const unsigned so = (unsigned)i * roww_b + (unsigned)((r & 3) + 8 * (r >> 2)) * ldc_b;
+                    if constexpr (ES == 4) __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][r] + bv), rc, vo, so, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b16(f32_to_bf16_bits(acc[i][j][r] + bv), rc, vo, so, 0);
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = tile_n * BN + wn * 64 + j * 32 + (lane & 31);
