@@ -112,6 +112,9 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(const KCParams p, con
         // while the consumers run stage s-4, to its store during stage s-1): the 7 MB weight pack does not stay in a 4 MB L2,
         // so a tile often comes from the Infinity Cache, and with two stages of lead the producers reached the barrier late
         // (ablation: 15 % of the kernel's time was staging the consumers waited for).
+        // Tried and measured neutral on a same-box A/B (1.2176 vs 1.2168 ms): a ring of THREE weight slots (stage s + 2
+        // stored during stage s) with the consumers fetching the first fragments of stage s + 1 before the barrier that
+        // ends stage s — the LDS latency behind the barrier is not what limits this kernel.
 #define HB_STEP(sg_, RP_NEXT)   /* the consumers run stage sg_; RP_NEXT = set (sg_ + 1) % 4 */                   \
     {                                                                                                      \
         if ((sg_) + 1 < nst) {                                                                             \
