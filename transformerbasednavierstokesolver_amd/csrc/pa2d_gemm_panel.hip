@@ -17,7 +17,9 @@
 // the HBM write of C); loads + convert alone 0.062; loads alone 0.046; nothing but barriers and the epilogue 0.023.
 // The producers' VALU conversion and the consumers' MFMAs add up instead of overlapping (same finding as on the conv),
 // which is what the plane-image operands remove on the conv path.  Starting every second pair of workgroups 3-12 us late
-// (so that their epilogue writes fall into the other half's K loops) measured neutral.
+// (so that their epilogue writes fall into the other half's K loops) measured neutral.  Pre-split weights (a plane image made
+// once per iteration, copied by the producers instead of converted) measured 0.4 % SLOWER on the whole step in a same-box
+// A/B: the weight conversion is not what the layer waits for, and the image is 1.5x the bytes.
 #include "pa2d_gemm_common.h"
 
 namespace {
