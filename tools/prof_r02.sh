@@ -1,5 +1,9 @@
 # Round-2 profile collection (run on the GPU box through gpurun): kernel-stats of the bench per reported engine, the kbench
 # table, and the PMC passes (one counter group per run, never combined with sys/hip traces) of the dense kernels.
+# profiles/r02_b_* came from this script as it stands; r02_c_* / r02_e_* are its two `rocprofv3 --kernel-trace --stats`
+# lines re-run at later commits, followed by an un-profiled `python bench.py` on the same box (profiles/README.md has
+# the exact command of every file).  A/B of one translation unit on one box: build the other variant into a second .so
+# and run `PA2D_LIB=/path/to/other.so python bench.py ...` next to the default in the same gpurun call.
 set -x
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r02_prof_b
