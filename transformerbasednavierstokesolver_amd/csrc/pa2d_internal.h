@@ -144,6 +144,10 @@ template <> struct Act<float> {
     static __device__ __forceinline__ float4 bld4(__amdgpu_buffer_rsrc_t r, unsigned off) { return buf_load4(r, off); }
     static __device__ __forceinline__ float2 bld2(__amdgpu_buffer_rsrc_t r, unsigned off) { return buf_load2(r, off); }
     static __device__ __forceinline__ float bld1(__amdgpu_buffer_rsrc_t r, unsigned off) { return buf_load1(r, off); }
+    // with a wave-uniform scalar offset added to the address (not to the range check: mask through `off`)
+    static __device__ __forceinline__ float bld1s(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) {
+        return __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(r, off, soff, 0));
+    }
     static __device__ __forceinline__ void bst4(__amdgpu_buffer_rsrc_t r, unsigned off, float4 v) { buf_store4(r, off, v); }
     static __device__ __forceinline__ void bst1(__amdgpu_buffer_rsrc_t r, unsigned off, float v) { buf_store1(r, off, v); }
 };
@@ -177,6 +181,9 @@ template <> struct Act<bf16_t> {
     }
     static __device__ __forceinline__ float bld1(__amdgpu_buffer_rsrc_t r, unsigned off) {
         return bf16_bits_to_f32(__builtin_amdgcn_raw_buffer_load_b16(r, off, 0, 0));
+    }
+    static __device__ __forceinline__ float bld1s(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned soff) {
+        return bf16_bits_to_f32(__builtin_amdgcn_raw_buffer_load_b16(r, off, soff, 0));
     }
     static __device__ __forceinline__ void bst4(__amdgpu_buffer_rsrc_t r, unsigned off, float4 v) {
         typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));

@@ -776,19 +776,19 @@ extern "C" {
 
 // number of point chunks per (batch, head) and points per chunk used by every slice-stage kernel
 int pa2d_slice_nchunk(int B, int N, int heads) {
-    // enough chunks to fill the CUs at small batch, but at most 16 (the token kernel fetches the chunk
-    // partials of an element 16 at a time) and at least 256 points per workgroup (4 groups per wave in flight)
+    // one WAVE of the v3 kernels owns a (batch, head, chunk) unit: enough units for two waves on each of the 1024 SIMDs,
+    // at least 128 points (4 groups of 32) per unit; the token kernels sum any number of chunk records
     const int bh = B * heads > 0 ? B * heads : 1;
     if (N < 1) return 1;
-    int nchunk = ceil_div(1024, bh);
-    int maxc = ceil_div(N, 256);
-    if (maxc > 16) maxc = 16;
+    static const int dbg_target = [] { const char* e = getenv("PA2D_DBG_NCHUNK_TARGET"); return e ? atoi(e) : 2048; }();   // DEV
+    int nchunk = ceil_div(dbg_target, bh);
+    const int maxc = ceil_div(N, 128);
     if (nchunk > maxc) nchunk = maxc;
     if (nchunk < 1) nchunk = 1;
-    int ppc = ceil_div(ceil_div(N, nchunk), 16) * 16;
+    const int ppc = ceil_div(ceil_div(N, nchunk), 32) * 32;
     return ceil_div(N, ppc);
 }
-static int ppc_for(int N, int nchunk) { return ceil_div(ceil_div(N, nchunk), 16) * 16; }
+static int ppc_for(int N, int nchunk) { return ceil_div(ceil_div(N, nchunk), 32) * 32; }
 // bf16-MFMA forms of the forward kernels (pa2d_slice_bf.hip): the default; PA2D_SLICE_MFMA=f32 keeps the exact-fp32-MFMA
 // kernels of this file (A/B timing, and the reference the new ones are tested against)
 __attribute__((visibility("hidden"))) int pa2d_launch_scatter_bf(const void* xm, long long ldx, const void* v, long long ldv, const float* ws, const float* bs,
@@ -798,6 +798,14 @@ __attribute__((visibility("hidden"))) int pa2d_launch_scatter_bf(const void* xm,
 __attribute__((visibility("hidden"))) int pa2d_launch_deslice_bf(const void* xm, long long ldx, const float* o, const float* ws, const float* bs,
                            const float* temperature, void* y, long long ldy, int B, int N, int heads, int D, int M, int mt,
                            int nchunk, int ppc, unsigned x_bytes, unsigned y_bytes, int clamp, int xcd_map, bool bf, hipStream_t st);
+__attribute__((visibility("hidden"))) int pa2d_launch_scatter3(const void* xm, long long ldx, const void* v, long long ldv, const float* ws, const float* bs,
+                           const float* temperature, float* spart, float* npart, int B, int N, int heads, int D, int M,
+                           int mt, int nchunk, int ppc, unsigned x_bytes, unsigned v_bytes, int clamp, int xcd_map, bool bf,
+                           hipStream_t st);
+static int slice_version() {          // development switch: PA2D_SLICE_V=2 keeps the round-2 bf16-MFMA kernels
+    static const int v = [] { const char* e = getenv("PA2D_SLICE_V"); return (e && e[0] == '2') ? 2 : 3; }();
+    return v;
+}
 static int slice_xcd_map() {          // PA2D_SLICE_MAP=legacy keeps the chunk-fastest numbering (A/B timing)
     const char* e = getenv("PA2D_SLICE_MAP");
     return (e && e[0] == 'l') ? 0 : 1;
@@ -834,7 +842,11 @@ static int slice_scatter_impl(const void* xm, long long ldx, const void* v, long
     }
     const int grid = B * heads * p.nchunk;
     if (ev_start && hipEventRecord(ev_start, st) != hipSuccess) return PA2D_ERR_ARG;
-    if (slice_on_bf16_mfma(true, bf)) {
+    if (slice_on_bf16_mfma(true, bf) && slice_version() == 3) {
+        const int rc = pa2d_launch_scatter3(xm, ldx, v, ldv, ws, bs, temperature, spart, npart, B, N, heads, D, M, mt,
+                                            p.nchunk, p.ppc, p.x_bytes, p.v_bytes, clamp_temperature, p.xcd_map, bf, st);
+        if (rc) return rc;
+    } else if (slice_on_bf16_mfma(true, bf)) {
         const int rc = pa2d_launch_scatter_bf(xm, ldx, v, ldv, ws, bs, temperature, spart, npart, B, N, heads, D, M, mt,
                                               p.nchunk, p.ppc, p.x_bytes, p.v_bytes, clamp_temperature, p.xcd_map, bf, st);
         if (rc) return rc;
