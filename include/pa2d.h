@@ -186,7 +186,9 @@ int pa2d_rel_l2_bwd(const float* pred, const float* y, const float* dnorm, const
  * pa2d_conv3x3x2_fwd/bwd make it from the fp32 tensor in a pre-pass; with the entry points below the PRODUCER of the
  * operand writes the image and nothing else: LayerNorm forward (…_2D.py:70 feeding Physics_Attention.py:94,96) and the
  * slice backward (autograd of Physics_Attention.py:98-101 feeding the autograd of :94,96), which also yields the conv
- * bias gradients.  Use when pa2d_conv3x3x2_planes_mask(...) == 7. */
+ * bias gradients (`nrm` [B*heads, M] = the forward's slice norms, pa2d_token_attn_fwd: the column sums of dF are
+ * sum_m nrm[m] dS[m][:], those of dX sum_m dbs_partial[m] Ws[m][:] — token-level sums, no pass over the points).
+ * Use when pa2d_conv3x3x2_planes_mask(...) == 7. */
 size_t pa2d_planes_bytes(long long rows, int C, int engine);
 int pa2d_conv3x3x2_planes_mask(int B, int H, int W, int C, int engine);
 int pa2d_layernorm_fwd_planes(const float* x, const float* gamma, const float* beta, void* planes, float* mean,
@@ -201,8 +203,8 @@ int pa2d_conv3x3x2_bwd_planes(const void* dout_planes, const void* xn_planes, co
                               void* ev_stop);
 int pa2d_slice_bwd_points_planes(const float* xm, long long ldx, const float* fm, long long ldf, const float* dy,
                                  long long lddy, const float* ws, const float* bs, const float* temperature,
-                                 const float* o, const float* ds, const float* dn, void* dxf_planes, float* dbx,
-                                 float* dbf, float* dws, float* dbs, float* dtemperature, void* ws_buf,
+                                 const float* o, const float* ds, const float* dn, const float* nrm, void* dxf_planes,
+                                 float* dbx, float* dbf, float* dws, float* dbs, float* dtemperature, void* ws_buf,
                                  size_t ws_bytes, int B, int N, int heads, int D, int M, int clamp_temperature,
                                  int accumulate, int engine, pa2d_stream_t stream, void* ev_start, void* ev_stop);
 

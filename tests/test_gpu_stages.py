@@ -414,10 +414,11 @@ def test_operand_planes_interface(dev, engine, nt):
     dopart, _ = ops.slice_scatter(xf, 2 * C, 0, dy, C, 0, g(ws), g(bs), g(temp), B, N, heads, D, M, want_norm=False)
     ds, dn, *_ = ops.token_attn_bwd(s_, nrm, g(wq), g(wk), g(wv), dopart)
     dxf, dws, dbs, dtemp = ops.slice_bwd_points(xf, dy, g(ws), g(bs), g(temp), o, ds, dn, B, N, heads, D, M)
-    dxfp, dbx, dbf, dws2, dbs2, dtemp2 = ops.slice_bwd_points_planes(xf, dy, g(ws), g(bs), g(temp), o, ds, dn, B, N, heads,
+    dxfp, dbx, dbf, dws2, dbs2, dtemp2 = ops.slice_bwd_points_planes(xf, dy, g(ws), g(bs), g(temp), o, ds, dn, nrm, B, N, heads,
                                                                      D, M, engine)
     assert rel_l2(_unplane(dxfp, B * N, 2 * C, nt), dxf.view(B * N, 2 * C)) < tol
-    assert torch.equal(dws, dws2) and torch.equal(dbs, dbs2) and torch.equal(dtemp, dtemp2)
+    # the plain and the planes form are two instantiations of one kernel template: same sums, not the same instruction stream
+    assert rel_l2(dws2, dws) < 1e-6 and rel_l2(dbs2, dbs) < 1e-6 and rel_l2(dtemp2, dtemp) < 1e-6
     colsum = dxf.view(B * N, 2 * C).double().sum(0)
     assert rel_l2(dbx, colsum[:C]) < 1e-5 and rel_l2(dbf, colsum[C:]) < 1e-5
     # conv backward from the two plane images == conv backward from fp32 tensors
@@ -427,6 +428,6 @@ def test_operand_planes_interface(dev, engine, nt):
     assert rel_l2(dbx, dbx_ref) < 1e-5 and rel_l2(dbf, dbf_ref) < 1e-5
     # accumulate flag
     into = tuple(torch.full_like(t, 0.25) for t in (dbx, dbf, dws, dbs, dtemp))
-    ops.slice_bwd_points_planes(xf, dy, g(ws), g(bs), g(temp), o, ds, dn, B, N, heads, D, M, engine, into=into)
+    ops.slice_bwd_points_planes(xf, dy, g(ws), g(bs), g(temp), o, ds, dn, nrm, B, N, heads, D, M, engine, into=into)
     for got, ref in zip(into, (dbx, dbf, dws, dbs, dtemp)):
         assert rel_l2(got - 0.25, ref) < 1e-5

@@ -89,7 +89,7 @@ def main():
         nt = 3 if E == ops.ENGINE_SPLIT else 1
         # the forms the model runs on the bf16 engines: LayerNorm and the slice backward write the conv's plane image
         tests["ln_fwd_planes"] = (lambda: ops.layernorm_fwd_planes(x2d, gamma, beta, E), (1.0 + nt * 0.5) * R * C * 4, "GB")
-        tests["slice_bwd_planes"] = (lambda: ops.slice_bwd_points_planes(xf, dy3, ws, bs, temp, o, ds, dn, B, N, heads, D, M, E),
+        tests["slice_bwd_planes"] = (lambda: ops.slice_bwd_points_planes(xf, dy3, ws, bs, temp, o, ds, dn, nrm, B, N, heads, D, M, E),
                                      (3.0 + nt * 1.0) * R * C * 4, "GB")
     for name, (fn, work, unit) in tests.items():
         if only and name not in only:

@@ -42,6 +42,10 @@
 #define I_PERM(n) "v_perm_b32 %" #n ", %8, %9, %8\n\t"
 #define I_CND(n) "v_cndmask_b32 %" #n ", %8, %9, vcc\n\t"
 #define I_NOP(n) "s_nop 0\n\t"
+#define I_CND64(n) "v_cndmask_b32_e64 %" #n ", %8, %9, s[10:11]\n\t"
+#define I_OR(n) "v_or_b32 %" #n ", %8, %9\n\t"
+#define I_CMP(n) "v_cmp_lt_i32 vcc, %8, %9\n\t"
+#define I_CMPCND(n) "v_cmp_lt_i32 vcc, %8, %9\n\tv_cndmask_b32 %" #n ", %8, %9, vcc\n\t"
 
 KERNEL(k_add, ASM1(BODY32(I_ADD)))
 KERNEL(k_fma, ASM1(BODY32(I_FMA)))
@@ -57,6 +61,10 @@ KERNEL(k_mov, ASM1(BODY32(I_MOV)))
 KERNEL(k_perm, ASM1(BODY32(I_PERM)))
 KERNEL(k_cnd, ASM1(BODY32(I_CND)))
 KERNEL(k_nop, ASM1(BODY32(I_NOP)))
+KERNEL(k_cnd64, asm volatile(BODY32(I_CND64) : OPS8(0) : "v"(b0), "v"(b1) : "s10", "s11");)
+KERNEL(k_or, ASM1(BODY32(I_OR)))
+KERNEL(k_cmp, asm volatile(BODY32(I_CMP) : OPS8(0) : "v"(b0), "v"(b1) : "vcc");)
+KERNEL(k_cmpcnd, asm volatile(BODY32(I_CMPCND) : OPS8(0) : "v"(b0), "v"(b1) : "vcc");)
 
 // packed f32: 64-bit operands
 #define PK8 "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7)
@@ -111,6 +119,49 @@ __global__ void k_mfma(unsigned long long* out, float seed) {
     if ((threadIdx.x & 63) == 0) out[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
 }
 
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+__global__ void k_mfma16(unsigned long long* out, float seed) {
+    bf16x4 a, b;
+    for (int i = 0; i < 4; ++i) { a[i] = (__bf16)(seed + i); b[i] = (__bf16)(seed - i); }
+    f32x4 c0 = {0, 0, 0, 0}, c1 = c0, c2 = c0, c3 = c0;
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < REP; ++i) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            asm volatile("v_mfma_f32_16x16x16_bf16 %0, %4, %5, %0\n\t"
+                         "v_mfma_f32_16x16x16_bf16 %1, %4, %5, %1\n\t"
+                         "v_mfma_f32_16x16x16_bf16 %2, %4, %5, %2\n\t"
+                         "v_mfma_f32_16x16x16_bf16 %3, %4, %5, %3\n\t"
+                         : "+v"(c0), "+v"(c1), "+v"(c2), "+v"(c3) : "v"(a), "v"(b));
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (c0[0] + c1[1] + c2[2] + c3[3] == 123.456f) out[1000000] = 0;
+    if ((threadIdx.x & 63) == 0) out[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
+}
+// one accumulator, dependent chain
+__global__ void k_mfma_dep(unsigned long long* out, float seed) {
+    bf16x8 a, b;
+    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(seed + i); b[i] = (__bf16)(seed - i); }
+    f32x4 c0 = {0, 0, 0, 0};
+    __syncthreads();
+    const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+    for (int i = 0; i < REP; ++i) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\t"
+                         "v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\t"
+                         "v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\t"
+                         "v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0\n\t"
+                         : "+v"(c0) : "v"(a), "v"(b));
+        }
+    }
+    const unsigned long long t1 = __builtin_amdgcn_s_memtime();
+    if (c0[0] == 123.456f) out[1000000] = 0;
+    if ((threadIdx.x & 63) == 0) out[blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)] = t1 - t0;
+}
+
 template <typename K>
 static void run(const char* name, K kern, int instr_per_wave, unsigned long long* d_out) {
     for (int wps = 1; wps <= 4; wps *= 2) {          // waves per SIMD: block = 256 * wps threads, one block per CU
@@ -136,9 +187,11 @@ int main() {
     run("v_lshl", k_shl, n, d_out); run("cvt_pk", k_cvt, n, d_out); run("v_exp", k_exp, n, d_out);
     run("v_rcp", k_rcp, n, d_out); run("v_max3", k_max3, n, d_out); run("max_dpp", k_dpp, n, d_out);
     run("add_dppm", k_dppm, n, d_out); run("v_mov", k_mov, n, d_out); run("v_perm", k_perm, n, d_out);
-    run("v_cndmask", k_cnd, n, d_out); run("s_nop0", k_nop, n, d_out);
+    run("v_cndmask", k_cnd, n, d_out); run("s_nop0", k_nop, n, d_out); run("cndmask_s", k_cnd64, n, d_out); run("v_or", k_or, n, d_out); run("v_cmp", k_cmp, n, d_out); run("cmp+cnd", k_cmpcnd, n, d_out);
     run("pk_add", k_pkadd, n, d_out); run("pk_fma", k_pkfma, n, d_out); run("pk_mul", k_pkmul, n, d_out);
     run("mfma", k_mfma<0>, REP * 32, d_out);
+    run("mfma16x16x16", k_mfma16, REP * 32, d_out);
+    run("mfma_dep", k_mfma_dep, REP * 32, d_out);
     run("mfma+1add", k_mfma<1>, REP * 32, d_out);      // per MFMA; each MFMA comes with NADD v_add
     run("mfma+2add", k_mfma<2>, REP * 32, d_out);
     run("mfma+4add", k_mfma<4>, REP * 32, d_out);

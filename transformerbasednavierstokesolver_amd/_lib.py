@@ -69,7 +69,7 @@ SIGNATURES.update({
     "pa2d_conv3x3x2_fwd_planes": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _i, _i, _st, _st, _st]),
     "pa2d_conv3x3x2_workspace_planes": (_sz, [_i, _i, _i, _i, _i]),
     "pa2d_conv3x3x2_bwd_planes": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _i, _i, _i, _st, _st, _st]),
-    "pa2d_slice_bwd_points_planes": (_i, [_f, _ll, _f, _ll, _f, _ll, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f,
+    "pa2d_slice_bwd_points_planes": (_i, [_f, _ll, _f, _ll, _f, _ll, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f,
                                           _sz, _i, _i, _i, _i, _i, _i, _i, _i, _st, _st, _st]),
     "pa2d_gemm_bias_act_fwd_bf16": (_i, [_f, _ll, _f, _ll, _f, _f, _ll, _f, _ll, _f, _ll, _i, _i, _i, _i, _st]),
     "pa2d_gemm_bwd_data_bf16": (_i, [_f, _ll, _f, _ll, _f, _ll, _i, _f, _ll, _f, _i, _i, _i, _st]),

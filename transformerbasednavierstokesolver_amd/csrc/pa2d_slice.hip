@@ -802,6 +802,27 @@ __attribute__((visibility("hidden"))) int pa2d_launch_scatter3(const void* xm, l
                            const float* temperature, float* spart, float* npart, int B, int N, int heads, int D, int M,
                            int mt, int nchunk, int ppc, unsigned x_bytes, unsigned v_bytes, int clamp, int xcd_map, bool bf,
                            hipStream_t st);
+__attribute__((visibility("hidden"))) int pa2d_launch_deslice3(const void* xm, long long ldx, const float* o, const float* ws, const float* bs,
+                           const float* temperature, void* y, long long ldy, int B, int N, int heads, int D, int M, int mt,
+                           int nchunk, int ppc, unsigned x_bytes, unsigned y_bytes, int clamp, bool bf, hipStream_t st);
+__attribute__((visibility("hidden"))) int pa2d_launch_slice_bwd3(
+    const void* xm, long long ldx, const void* fm, long long ldf, const void* dy, long long lddy, const float* ws,
+    const float* bs, const float* temperature, const float* o, const float* ds, const float* dn, const float* nrm, void* dxm,
+    long long lddx, void* dfm, long long lddf, void* planes, unsigned planes_bytes, int planes_nt, int stride, float* part,
+    int B, int N, int heads, int D, int M, int mt, int nchunk, int ppc, unsigned x_bytes, unsigned f_bytes,
+    unsigned dy_bytes, unsigned dx_bytes, unsigned df_bytes, int clamp, int xcd_map, bool bf, hipStream_t st);
+// chunking of the slice BACKWARD kernel (its partial-sum records are its own): one 4-wave workgroup per (batch, head,
+// chunk), about two workgroups per CU in one round, at least 128 points per workgroup
+static int bwd_nchunk(int B, int N, int heads) {
+    const int bh = B * heads > 0 ? B * heads : 1;
+    if (N < 1) return 1;
+    int nchunk = ceil_div(512, bh);
+    const int maxc = ceil_div(N, 128);
+    if (nchunk > maxc) nchunk = maxc;
+    if (nchunk < 1) nchunk = 1;
+    const int ppc = ceil_div(ceil_div(N, nchunk), 32) * 32;
+    return ceil_div(N, ppc);
+}
 static int slice_version() {          // development switch: PA2D_SLICE_V=2 keeps the round-2 bf16-MFMA kernels
     static const int v = [] { const char* e = getenv("PA2D_SLICE_V"); return (e && e[0] == '2') ? 2 : 3; }();
     return v;
@@ -880,7 +901,11 @@ static int deslice_impl(const void* xm, long long ldx, const float* o, const flo
     }
     const int grid = B * heads * p.nchunk;
     if (ev_start && hipEventRecord(ev_start, st) != hipSuccess) return PA2D_ERR_ARG;
-    if (slice_on_bf16_mfma(false, bf)) {
+    if (slice_on_bf16_mfma(false, bf) && slice_version() == 3) {
+        const int rc = pa2d_launch_deslice3(xm, ldx, o, ws, bs, temperature, y, ldy, B, N, heads, D, M, mt, p.nchunk, p.ppc,
+                                            p.x_bytes, p.y_bytes, clamp_temperature, bf, st);
+        if (rc) return rc;
+    } else if (slice_on_bf16_mfma(false, bf)) {
         const int rc = pa2d_launch_deslice_bf(xm, ldx, o, ws, bs, temperature, y, ldy, B, N, heads, D, M, mt, p.nchunk, p.ppc,
                                               p.x_bytes, p.y_bytes, clamp_temperature, p.xcd_map, bf, st);
         if (rc) return rc;
@@ -900,7 +925,7 @@ static int slice_bwd_impl(const void* xm, long long ldx, const void* fm, long lo
                           float* dtemperature, void* ws_buf, size_t ws_bytes, int B, int N, int heads, int D, int M,
                           int clamp_temperature, int accumulate, hipStream_t st, hipEvent_t ev_start,
                           hipEvent_t ev_stop, bool bf, void* planes = nullptr, int planes_nt = 0, float* dbx = nullptr,
-                          float* dbf = nullptr) {
+                          float* dbf = nullptr, const float* nrm = nullptr) {
     const int mt = mt_for(M);
     if ((ldx & 3) || (ldf & 3) || (lddy & 3) || (lddx & 3) || (lddf & 3) || (D & 7)) return PA2D_ERR_ARG;
     if (B <= 0 || N <= 0) {
@@ -915,8 +940,8 @@ static int slice_bwd_impl(const void* xm, long long ldx, const void* fm, long lo
     p.xm = xm; p.ldx = ldx; p.fm = fm; p.ldf = ldf; p.dy = dy; p.lddy = lddy; p.ws = ws; p.bs = bs;
     p.temperature = temperature; p.o = o; p.ds = ds; p.dn = dn; p.dxm = dxm; p.lddx = lddx; p.dfm = dfm;
     p.lddf = lddf; p.part = (float*)ws_buf; p.B = B; p.N = N; p.heads = heads; p.M = M; p.clamp = clamp_temperature;
-    p.xcd_map = slice_xcd_map(); p.xcd_map = slice_xcd_map();
-    p.nchunk = pa2d_slice_nchunk(B, N, heads);
+    p.xcd_map = slice_xcd_map();
+    p.nchunk = bwd_nchunk(B, N, heads);
     p.ppc = ppc_for(N, p.nchunk);
     p.stride = M * D + M + 1 + 2 * D;
     p.planes = planes; p.planes_nt = planes ? planes_nt : 0; p.planes_bytes = 0;
@@ -941,8 +966,19 @@ static int slice_bwd_impl(const void* xm, long long ldx, const void* fm, long lo
     const int grid = B * heads * p.nchunk;
     int rc = PA2D_OK;
     if (ev_start && hipEventRecord(ev_start, st) != hipSuccess) return PA2D_ERR_ARG;
+    if (slice_on_bf16_mfma(false, bf) && slice_version() == 3) {
+        if (planes && !nrm) return PA2D_ERR_ARG;
+        rc = pa2d_launch_slice_bwd3(p.xm, p.ldx, p.fm, p.ldf, p.dy, p.lddy, ws, bs, temperature, o, ds, dn, nrm, p.dxm, p.lddx, p.dfm,
+                                    p.lddf, p.planes, p.planes_bytes, p.planes_nt, p.stride, p.part, B, N, heads, D, M, mt,
+                                    p.nchunk, p.ppc, p.x_bytes, p.f_bytes, p.dy_bytes, p.dx_bytes, p.df_bytes,
+                                    clamp_temperature, p.xcd_map, bf, st);
+    } else {
+        rc = PA2D_ERR_UNSUPPORTED;
+    }
+    if (rc == PA2D_ERR_UNSUPPORTED) {
 #define CALL_BW(D_, MT_) rc = launch_bwd_t<D_, MT_>(p, grid, st, bf)
-    DISPATCH_D(CALL_BW)
+        DISPATCH_D(CALL_BW)
+    }
     if (rc) return rc;
     PA2D_CHECK_LAUNCH();
     if (ev_stop && hipEventRecord(ev_stop, st) != hipSuccess) return PA2D_ERR_ARG;
@@ -995,7 +1031,7 @@ int pa2d_deslice_fwd_bf16(const void* xm, long long ldx, const float* o, const f
 }
 
 size_t pa2d_slice_bwd_workspace(int B, int N, int heads, int D, int M) {
-    const int nchunk = pa2d_slice_nchunk(B, N, heads);
+    const int nchunk = bwd_nchunk(B, N, heads);
     return sizeof(float) * ((size_t)B * heads * nchunk + 1) * ((size_t)M * D + M + 1 + 2 * D);
 }
 
@@ -1026,15 +1062,15 @@ int pa2d_slice_bwd_points_bf16(const void* xm, long long ldx, const void* fm, lo
 // same partial-sum records.
 int pa2d_slice_bwd_points_planes(const float* xm, long long ldx, const float* fm, long long ldf, const float* dy,
                                  long long lddy, const float* ws, const float* bs, const float* temperature,
-                                 const float* o, const float* ds, const float* dn, void* dxf_planes, float* dbx,
-                                 float* dbf, float* dws, float* dbs, float* dtemperature, void* ws_buf, size_t ws_bytes,
-                                 int B, int N, int heads, int D, int M, int clamp_temperature, int accumulate, int engine,
-                                 hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
+                                 const float* o, const float* ds, const float* dn, const float* nrm, void* dxf_planes,
+                                 float* dbx, float* dbf, float* dws, float* dbs, float* dtemperature, void* ws_buf,
+                                 size_t ws_bytes, int B, int N, int heads, int D, int M, int clamp_temperature,
+                                 int accumulate, int engine, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (engine != 1 && engine != 2) return PA2D_ERR_ARG;
-    if (!dxf_planes || !dbx || !dbf) return PA2D_ERR_ARG;
+    if (!dxf_planes || !dbx || !dbf || !nrm) return PA2D_ERR_ARG;
     return slice_bwd_impl(xm, ldx, fm, ldf, dy, lddy, ws, bs, temperature, o, ds, dn, nullptr, 0, nullptr, 0, dws, dbs,
                           dtemperature, ws_buf, ws_bytes, B, N, heads, D, M, clamp_temperature, accumulate, st, ev_start,
-                          ev_stop, false, dxf_planes, engine == 2 ? 1 : 3, dbx, dbf);
+                          ev_stop, false, dxf_planes, engine == 2 ? 1 : 3, dbx, dbf, nrm);
 }
 
 }  // extern "C"

@@ -1,0 +1,678 @@
+// Slice backward (phase C) on the bf16 matrix cores — gfx950 / CDNA4.
+//
+// Round 2's slice_bwd_kernel evaluates its six contractions on v_mfma_f32_16x16x4_f32 (64 FLOP/clk/SIMD): the fp32 matrix
+// pipe was busy 53 % of the GPU cycles and the waves waited on issue 53 % of theirs (profiles/r02_e_pmc_slice_kernels.json).
+// Here every contraction runs on v_mfma_f32_16x16x32_bf16 as six terms of the exact 3-plane operand splits (fp32
+// accumulation, a 24-bit significand: the fp32-accurate scheme of the forward kernels in pa2d_slice3.hip):
+//   Z^T  = Ws . X^T                 (rows = slices, cols = points; C operand = bs)
+//   dW^T = O . dY^T + dS . F^T      (C operand = dn)
+//   softmax over the slices in-lane (+ two row swaps), dL = W * (dW - rowsum(dW * W))
+//   dF^T = dS^T . W^T ;  dX^T = Ws^T . dL^T / tau       (rows = channels, cols = points)
+//   dWs += dL^T . X                 (k = points)
+// Parameter operands: Ws, O, dS are split ONCE per workgroup into bf16 plane images in LDS, [plane][slice][d]; one image
+// serves both orientations — row = slice fragments are plain 16-byte reads, row = channel fragments (dS^T, Ws^T) are
+// transposed reads (ds_read_b64_tr_b16).  dWs contracts over the point index, which sits on the lanes of both dL and X:
+// the wave writes the planes of X (once per group of 32 points) and of dL (32 slices at a time) to a private LDS scratch
+// in [point][column] order and reads both operands back transposed.
+#include "pa2d_internal.h"
+#include <type_traits>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+#ifdef S3B_NOBAR
+#define S3B_BARRIER
+#else
+#define S3B_BARRIER __builtin_amdgcn_sched_barrier(0);
+#endif
+#define NEG_BIG (-1e30f)
+#define LOG2E 1.44269504088896340736f
+
+namespace {
+
+__device__ __forceinline__ f32x4 mfma_bf(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float clamp_tau(float t) { return fminf(fmaxf(t, 0.1f), 5.0f); }
+__device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+// reductions over the four lane groups l, l ^ 16, l ^ 32, l ^ 48 (see pa2d_slice3.hip)
+#define KQ_OP(OP)                                                                                            \
+    float t;                                                                                                 \
+    asm volatile("v_mov_b32 %1, %0\n\t"                                                                      \
+                 "s_nop 1\n\t"                                                                               \
+                 "v_permlane16_swap_b32 %0, %1\n\t"                                                          \
+                 OP " %0, %0, %1\n\t"                                                                        \
+                 "v_mov_b32 %1, %0\n\t"                                                                      \
+                 "s_nop 1\n\t"                                                                               \
+                 "v_permlane32_swap_b32 %0, %1\n\t"                                                          \
+                 OP " %0, %0, %1\n\t"                                                                        \
+                 "s_nop 0"                                                                                   \
+                 : "+v"(v), "=&v"(t));                                                                       \
+    return v
+__device__ __forceinline__ float kq_max(float v) { KQ_OP("v_max_f32"); }
+__device__ __forceinline__ float kq_sum(float v) { KQ_OP("v_add_f32"); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {      // epilogue only
+    v += dpp_mov<0xB1>(v); v += dpp_mov<0x4E>(v); v += dpp_mov<0x141>(v); v += dpp_mov<0x140>(v);
+    return v;
+}
+
+// exact split of 8 floats into NP bf16 planes (pa2d_slice3.hip)
+template <int NP>
+__device__ __forceinline__ void split8(const f32x8 x, bf16x8 (&pl)[NP]) {
+    u32x4 p0, p1, p2;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x2 a = {x[2 * q], x[2 * q + 1]};
+        const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(a, bf16x2));
+        p0[q] = h;
+        if constexpr (NP > 1) {
+            const f32x2 hf = {__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)};
+            const f32x2 r = a - hf;
+            const unsigned m = __builtin_bit_cast(unsigned, __builtin_convertvector(r, bf16x2));
+            p1[q] = m;
+            if constexpr (NP > 2) {
+                const f32x2 mf = {__uint_as_float(m << 16), __uint_as_float(m & 0xffff0000u)};
+                p2[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(r - mf, bf16x2));
+            }
+        }
+    }
+    pl[0] = __builtin_bit_cast(bf16x8, p0);
+    if constexpr (NP > 1) pl[1] = __builtin_bit_cast(bf16x8, p1);
+    if constexpr (NP > 2) pl[2] = __builtin_bit_cast(bf16x8, p2);
+}
+
+template <typename T> struct Planes;
+template <> struct Planes<float> { static constexpr int ACT = 3, WGT = 3; };
+template <> struct Planes<bf16_t> { static constexpr int ACT = 1, WGT = 2; };
+
+// acc + sum over the kept terms a[i] * b[j] (i + j <= 2, smallest first)
+template <int NA, int NB>
+__device__ __forceinline__ f32x4 mfma_terms(const bf16x8 (&a)[NA], const bf16x8 (&b)[NB], f32x4 acc) {
+#pragma unroll
+    for (int s = 2; s >= 0; --s)
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int j = s - i;
+            if (j >= 0 && j < NB) acc = mfma_bf(a[i], b[j], acc);
+        }
+    return acc;
+}
+
+// k-fragment of one activation row: 8 consecutive elements d = 32 s + 8 kq .. + 7, raw
+template <typename T> struct Raw8;
+template <> struct Raw8<float> { float4 a, b; };
+template <> struct Raw8<bf16_t> { u32x4 q; };
+template <typename T>
+__device__ __forceinline__ void load_raw8(__amdgpu_buffer_rsrc_t r, unsigned off, Raw8<T>& x) {
+    if constexpr (sizeof(T) == 2) {
+        x.q = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    } else {
+        x.a = buf_load4(r, off);
+        x.b = buf_load4(r, off == OOB_OFF ? OOB_OFF : off + 16u);
+    }
+}
+template <typename T>
+__device__ __forceinline__ void raw_planes(const Raw8<T>& x, bf16x8 (&pl)[Planes<T>::ACT]) {
+    if constexpr (sizeof(T) == 2) {
+        pl[0] = __builtin_bit_cast(bf16x8, x.q);
+    } else {
+        const f32x8 v = {x.a.x, x.a.y, x.a.z, x.a.w, x.b.x, x.b.y, x.b.z, x.b.w};
+        split8<3>(v, pl);
+    }
+}
+
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+// two transposed reads = one 8-element MFMA fragment (elements 0..3 from `a0`, 4..7 from `a1`)
+__device__ __forceinline__ bf16x8 tr_frag(const unsigned char* a0, const unsigned char* a1) {
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a0);
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)a1);
+    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+// chunk swizzle of the parameter images (64-byte rows): with c ^ 3 on rows 4..7 (mod 8) both the 16-byte row-fragment
+// reads (16 rows x 4 chunks per wave instruction) and the transposed 4-row x 32-byte block reads are bank-conflict free
+__device__ __forceinline__ constexpr int swz(int row) { return 3 * ((row >> 2) & 1); }
+
+template <int D, int MT> struct BwCfg {
+    static constexpr int KST = (D + 31) / 32;       // 32-wide k-steps of a contraction over d
+    static constexpr int KP = 32 * KST;             // d extent of the parameter images (zero padded)
+    static constexpr int DT = (D + 15) / 16;        // 16-wide tiles over d
+    static constexpr int DP = 16 * DT;
+    static constexpr int MU = (MT + 1) / 2;         // 32-slice k-steps of a contraction over the slices
+    static constexpr int MP = 32 * MU;              // slice extent of the images (zero padded)
+    static constexpr bool SWZ = KP == 32;           // 64-byte image rows, 16-byte chunk c stored at c ^ swz(row)
+    static constexpr int RP = SWZ ? KP : KP + 8;    // image row pitch (elements)
+    static constexpr int PIMG = MP * RP * 2;        // bytes of one plane image
+    static constexpr int XP = KP + 16;              // row pitch of the X scratch [16 points][d]: 96 B rows at D = 32
+    static constexpr int LP = MP + 16;              // row pitch of the dL scratch [16 points][slices]: 160 B rows at M = 64
+    static constexpr int SCR = 3 * 16 * (XP > LP ? XP : LP) * 2;      // scratch bytes per wave (X and dL alias)
+    static constexpr int IMGS = 9 * PIMG;                             // Ws, O, dS x 3 planes
+    static constexpr int SMEM = IMGS + 2 * MP * 4 + 4 * SCR;          // + bs, dn (fp32)
+};
+
+struct SliceBwd3Params {
+    const void* xm; long long ldx;
+    const void* fm; long long ldf;
+    const void* dy; long long lddy;
+    const float* ws; const float* bs; const float* temperature;
+    const float* o; const float* ds; const float* dn; const float* nrm;
+    void* dxm; long long lddx;
+    void* dfm; long long lddf;
+    void* planes; unsigned planes_bytes;
+    int stride;
+    float* part;
+    int B, N, heads, M, nchunk, ppc;
+    unsigned x_bytes, f_bytes, dy_bytes, dx_bytes, df_bytes;
+    int clamp, xcd_map;
+};
+
+}  // namespace
+
+// one workgroup (4 waves) = one (batch, head, point chunk); wave w takes the groups of 32 points w, w + 4, ...
+template <int D, int MT, typename T, int PL>
+__global__ __launch_bounds__(256, 2) void slice_bwd3_kernel(const SliceBwd3Params p) {
+    using C = BwCfg<D, MT>;
+    constexpr int KST = C::KST, DT = C::DT, MU = C::MU, MP = C::MP, DP = C::DP, RP = C::RP, PIMG = C::PIMG;
+    constexpr int XP = C::XP, LP = C::LP;
+    constexpr int NA = Planes<T>::ACT, NW = Planes<T>::WGT;
+    constexpr unsigned ES = Act<T>::ES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const img = smem;                                       // [mat 0..2 = Ws, O, dS][plane][MP][RP] bf16
+    float* const bsL = reinterpret_cast<float*>(smem + C::IMGS);          // [MP]
+    float* const dnL = bsL + MP;                                           // [MP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, kq = lane >> 4;
+    unsigned char* const scr = smem + C::IMGS + 2 * MP * 4 + wave * C::SCR;       // wave-private
+    int b, hh, chunk, bid;
+    if (!slice_decode(p.xcd_map, p.B, p.heads, p.nchunk, b, hh, chunk, bid)) return;
+    const float inv_tau = 1.0f / (p.clamp ? clamp_tau(p.temperature[hh]) : p.temperature[hh]);
+    const float scale = LOG2E * inv_tau;
+    const size_t bh = (size_t)(b * p.heads + hh);
+
+    // ---- parameter images: thread -> (slice m, 8 consecutive d) pieces of Ws, O, dS, split into 3 planes
+    for (int i = tid; i < MP * (C::KP / 8); i += 256) {
+        const int m = i / (C::KP / 8), d0 = 8 * (i % (C::KP / 8));
+        const float* src[3] = {p.ws + (size_t)m * D, p.o + (bh * p.M + m) * D, p.ds + (bh * p.M + m) * D};
+#pragma unroll
+        for (int mat = 0; mat < 3; ++mat) {
+            f32x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (m < p.M && d0 + e < D) ? src[mat][d0 + e] : 0.f;
+            bf16x8 pl[3];
+            split8<3>(v, pl);
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                *reinterpret_cast<bf16x8*>(img + (mat * 3 + q) * PIMG + m * RP * 2 + (C::SWZ ? ((d0 >> 3) ^ swz(m)) * 16 : d0 * 2)) = pl[q];
+        }
+    }
+    for (int i = tid; i < MP; i += 256) {
+        bsL[i] = i < p.M ? p.bs[i] : NEG_BIG;          // padding slices: weight exactly 0
+        dnL[i] = i < p.M ? p.dn[bh * p.M + i] : 0.f;
+    }
+    __syncthreads();
+
+    // lane-constant LDS byte offsets
+    // row fragment (A operand, row = slice 16 mt + li, k = d 32 s + 8 kq ..): + mt * 16 * RP * 2 + s * 64
+    const unsigned rowf = (unsigned)(li * RP * 2 + (C::SWZ ? (kq ^ swz(li)) * 16 : 8 * kq * 2));
+    // transposed fragment of an image (A operand, row = channel 16 dt + li, k-slot e of lane group kq = slice
+    // 32 u + 4 kq + e (e < 4) or 32 u + 16 + 4 kq + e - 4): block rows m0 = 32 u + 4 kq (+ 16), lane 4 q + pq of the
+    // group supplies row m0 + q, columns 16 dt + 4 pq ..: + u * 32 * RP * 2 + dt * 32 (+ 16 * RP * 2 for the second read)
+    const int q4 = li >> 2, pq = li & 3;
+    const unsigned trf = (unsigned)((4 * kq + q4) * RP * 2 + (C::SWZ ? 0 : 4 * pq * 2));
+    // SWZ: the 8-byte piece (chunk 2 dt + (pq >> 1), half pq & 1) of a row with swizzle 3 * (kq & 1)
+    auto trc = [&](int dt) -> unsigned { return C::SWZ ? (unsigned)((((2 * dt + (pq >> 1)) ^ (3 * (kq & 1))) * 16) + 8 * (pq & 1)) : (unsigned)(dt * 32); };
+    // transposed HALF fragments of the per-tile scratch images: the contraction over the 32 points of a group uses the
+    // k order (element e of lane group kq) = point 4 kq + e of tile 0 for e < 4, point 4 kq + e - 4 of tile 1 otherwise,
+    // so each tile contributes one transposed read (rows 4 kq + q, columns 4 pq ..) per fragment
+    const unsigned trx = (unsigned)(((4 * kq + q4) * XP + 4 * pq) * 2);
+    const unsigned trl = (unsigned)(((4 * kq + q4) * LP + 4 * pq) * 2);
+
+    f32x4 wsacc[MT][DT];
+    float dbacc[MT][4];
+    float dtacc = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dbacc[mt][r] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) wsacc[mt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+    const int Ctot = p.heads * D;
+    const int p_begin = chunk * p.ppc;
+    const int p_end = min(p.N, p_begin + p.ppc);
+    const unsigned row0 = (unsigned)b * (unsigned)p.N;
+    const __amdgpu_buffer_rsrc_t rx = make_rsrc_v(p.xm, p.x_bytes);
+    const __amdgpu_buffer_rsrc_t rf = make_rsrc_v(p.fm, p.f_bytes);
+    const __amdgpu_buffer_rsrc_t rg = make_rsrc_v(p.dy, p.dy_bytes);
+    const __amdgpu_buffer_rsrc_t rdx = make_rsrc_v(p.dxm, p.dx_bytes);
+    const __amdgpu_buffer_rsrc_t rdf = make_rsrc_v(p.dfm, p.df_bytes);
+    const __amdgpu_buffer_rsrc_t rpl = make_rsrc_v(PL ? p.planes : nullptr, PL ? p.planes_bytes : 0u);
+    const unsigned ldxb = (unsigned)p.ldx * ES, ldfb = (unsigned)p.ldf * ES, ldgb = (unsigned)p.lddy * ES;
+    const unsigned lddxb = (unsigned)p.lddx * ES, lddfb = (unsigned)p.lddf * ES, hcol = (unsigned)(hh * D) * ES;
+
+    Raw8<T> xr[KST], fr[KST], gr[KST];           // ONE tile in flight: reloaded as soon as its planes exist
+    auto load_tile = [&](int g_) {               // g_ = first point of the tile
+        const int pt_ = g_ + li;
+        const bool ok_ = pt_ < p_end;
+#pragma unroll
+        for (int s = 0; s < KST; ++s) {
+            const bool okd_ = 32 * s + 8 * kq < D;
+            const unsigned c_ = hcol + (32 * s + 8 * kq) * ES;
+            load_raw8<T>(rx, (ok_ && okd_) ? (row0 + pt_) * ldxb + c_ : OOB_OFF, xr[s]);
+            load_raw8<T>(rf, (ok_ && okd_) ? (row0 + pt_) * ldfb + c_ : OOB_OFF, fr[s]);
+            load_raw8<T>(rg, (ok_ && okd_) ? (row0 + pt_) * ldgb + c_ : OOB_OFF, gr[s]);
+        }
+    };
+    auto wave_sync = [&]() {                     // orders this wave's LDS stores and loads of the private scratch
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+
+    int g = p_begin + wave * 32;
+    if (g < p_end) load_tile(g);
+    for (; g < p_end; g += 128) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int pt = g + 16 * t + li;
+            const bool pv = pt < p_end;
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- Z^T = Ws . X^T, then dW^T = O . dY^T + dS . F^T (rows = slices 16 mt + 4 kq + r, cols = points); one
+            //      activation tensor is turned into planes at a time; X also goes to the scratch image [point][d].
+            //      The parameter fragments are read from LDS one (slice tile, k-step) ahead of the MFMAs that use them.
+            f32x4 z[MT], dw[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                z[mt] = *reinterpret_cast<const f32x4*>(bsL + 16 * mt + 4 * kq);
+                dw[mt] = *reinterpret_cast<const f32x4*>(dnL + 16 * mt + 4 * kq);
+            }
+            auto row_product = [&](int mat, const bf16x8 (&bpl)[KST][NA], f32x4 (&acc)[MT]) {
+                bf16x8 fr_[2][3];
+#pragma unroll
+                for (int q = 0; q < 3; ++q) fr_[0][q] = *reinterpret_cast<const bf16x8*>(img + (mat * 3 + q) * PIMG + rowf);
+#pragma unroll
+                for (int i = 0; i < MT * KST; ++i) {
+                    const int mt = i / KST, s_ = i % KST;
+                    if (i + 1 < MT * KST) {
+                        const int mt1 = (i + 1) / KST, s1 = (i + 1) % KST;
+#pragma unroll
+                        for (int q = 0; q < 3; ++q)
+                            fr_[(i + 1) & 1][q] = *reinterpret_cast<const bf16x8*>(img + (mat * 3 + q) * PIMG + rowf +
+                                                                                    (unsigned)(mt1 * 16 * RP * 2 + s1 * 64));
+                    }
+                    acc[mt] = mfma_terms<3, NA>(fr_[i & 1], bpl[s_], acc[mt]);
+                    S3B_BARRIER
+                }
+            };
+            {
+                bf16x8 xpl[KST][NA];
+#pragma unroll
+                for (int s = 0; s < KST; ++s) {
+                    raw_planes<T>(xr[s], xpl[s]);
+#pragma unroll
+                    for (int q = 0; q < NA; ++q)
+                        *reinterpret_cast<bf16x8*>(scr + q * 16 * XP * 2 + (li * XP + 32 * s + 8 * kq) * 2) = xpl[s][q];
+                }
+                row_product(0, xpl, z);
+            }
+            wave_sync();
+            s16x4 xTh[DT][NA];                   // X^T half fragments: channel 16 dt + li, points 4 kq .. 4 kq + 3 of this tile
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int q = 0; q < NA; ++q)
+                    xTh[dt][q] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(scr + q * 16 * XP * 2 + trx + dt * 32));
+            {
+                bf16x8 gpl[KST][NA];
+#pragma unroll
+                for (int s = 0; s < KST; ++s) raw_planes<T>(gr[s], gpl[s]);
+                row_product(1, gpl, dw);
+            }
+            {
+                bf16x8 fpl[KST][NA];
+#pragma unroll
+                for (int s = 0; s < KST; ++s) raw_planes<T>(fr[s], fpl[s]);
+                {   // next tile: t = 0 -> second tile of this group, t = 1 -> first tile of the wave's next group
+                    const int gn = t == 0 ? g + 16 : g + 128;
+                    if (gn < p_end) load_tile(gn);
+                }
+                row_product(2, fpl, dw);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- softmax over the slices of this lane's point, dL
+            float mx = z[0][0];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, z[mt][r]);
+            mx = kq_max(mx);
+            const float nm = -mx * scale;
+            f32x4 w[MT];
+            float sm = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = ex2(fmaf(z[mt][r], scale, nm));
+                    w[mt][r] = e;
+                    sm += e;
+                }
+            sm = kq_sum(sm);
+            const float inv = pv ? __builtin_amdgcn_rcpf(sm) : 0.f;
+            float rd = 0.f;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    w[mt][r] *= inv;
+                    rd = fmaf(dw[mt][r], w[mt][r], rd);
+                }
+            rd = kq_sum(rd);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float dl = w[mt][r] * (dw[mt][r] - rd);
+                    dw[mt][r] = dl;
+                    dbacc[mt][r] += dl;
+                    dtacc = fmaf(dl, z[mt][r], dtacc);       // padding slices: dl = 0 exactly (w = 0)
+                }
+            // ---- dF^T = dS^T . W^T ; dX^T = Ws^T . dL^T (rows = channels 16 dt + 4 kq + r', cols = points);
+            //      the dL planes go to the scratch image [point][slice] (the X image is dead: its fragments are in xTh)
+            f32x4 facc[DT], xacc[DT];
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                facc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                xacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            // B operands (k = slices of k-step u: elements 0..3 = slice tile 2u, 4..7 = slice tile 2u + 1)
+            auto slice_planes = [&](const f32x4 (&src)[MT], bf16x8 (&dst)[MU][NW]) {
+#pragma unroll
+                for (int u = 0; u < MU; ++u) {
+                    f32x8 v;
+                    const bool has = 2 * u + 1 < MT;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = src[2 * u][e];
+                        v[4 + e] = has ? src[has ? 2 * u + 1 : 0][e] : 0.f;
+                    }
+                    split8<NW>(v, dst[u]);
+                }
+            };
+            // transposed parameter fragments one (k-step, channel tile) ahead of their MFMAs
+            auto col_product = [&](int mat, const bf16x8 (&bpl)[MU][NW], f32x4 (&acc)[DT]) {
+                bf16x8 fr_[2][3];
+                auto rd_ = [&](int i, bf16x8 (&dst)[3]) {
+                    const int u = i / DT, dt = i % DT;
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) {
+                        const unsigned char* a_ = img + (mat * 3 + q) * PIMG + trf + (unsigned)(u * 32 * RP * 2) + trc(dt);
+                        dst[q] = tr_frag(a_, a_ + 16 * RP * 2);
+                    }
+                };
+                rd_(0, fr_[0]);
+#pragma unroll
+                for (int i = 0; i < MU * DT; ++i) {
+                    if (i + 1 < MU * DT) rd_(i + 1, fr_[(i + 1) & 1]);
+                    acc[i % DT] = mfma_terms<3, NW>(fr_[i & 1], bpl[i / DT], acc[i % DT]);
+                    S3B_BARRIER
+                }
+            };
+            {
+                bf16x8 wp[MU][NW];
+                slice_planes(w, wp);
+                col_product(2, wp, facc);
+            }
+            {
+                bf16x8 dlp[MU][NW];
+                slice_planes(dw, dlp);
+                // dL planes -> scratch [point][slice]: lane (point li, kq) holds the slices 32 u + 4 kq .. + 3 (elements
+                // 0..3) and 32 u + 16 + 4 kq .. + 3 (elements 4..7)
+#pragma unroll
+                for (int u = 0; u < MU; ++u)
+#pragma unroll
+                    for (int q = 0; q < NW; ++q) {
+                        const u32x4 v = __builtin_bit_cast(u32x4, dlp[u][q]);
+                        unsigned char* r_ = scr + q * 16 * LP * 2 + li * LP * 2 + (32 * u) * 2;
+                        *reinterpret_cast<u32x2*>(r_ + (4 * kq) * 2) = (u32x2){v.x, v.y};
+                        *reinterpret_cast<u32x2*>(r_ + (16 + 4 * kq) * 2) = (u32x2){v.z, v.w};
+                    }
+                col_product(0, dlp, xacc);
+            }
+            // ---- dWs += dL^T . X over the 16 points of the tile.  k = 16 points fill half of a 16x16x32 MFMA: the other half
+            //      carries a second plane pair, so the six terms of the 3 x 3 split are three MFMAs per output tile
+            //      (A = [p0|p0], [p1|p0], [p1|p2]; B = [x0|x1], [x0|x2], [x1|x0]), and nothing is kept across tiles.
+            wave_sync();
+            {
+                auto pair_ = [](s16x4 lo, s16x4 hi) {
+                    const s16x8 v = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                    return __builtin_bit_cast(bf16x8, v);
+                };
+                bf16x8 xB[DT][NA == 3 ? 3 : 1];
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) {
+                    if constexpr (NA == 3) {
+                        xB[dt][0] = pair_(xTh[dt][0], xTh[dt][1]);
+                        xB[dt][1] = pair_(xTh[dt][0], xTh[dt][2]);
+                        xB[dt][2] = pair_(xTh[dt][1], xTh[dt][0]);
+                    } else {
+                        xB[dt][0] = pair_(xTh[dt][0], xTh[dt][0]);
+                    }
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    s16x4 lh[NW];
+#pragma unroll
+                    for (int q = 0; q < NW; ++q)
+                        lh[q] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(scr + q * 16 * LP * 2 + trl + mt * 32));
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) {
+                        if constexpr (NA == 3 && NW == 3) {
+                            wsacc[mt][dt] = mfma_bf(pair_(lh[1], lh[2]), xB[dt][2], wsacc[mt][dt]);      // p1 x1 + p2 x0
+                            wsacc[mt][dt] = mfma_bf(pair_(lh[1], lh[0]), xB[dt][1], wsacc[mt][dt]);      // p1 x0 + p0 x2
+                            wsacc[mt][dt] = mfma_bf(pair_(lh[0], lh[0]), xB[dt][0], wsacc[mt][dt]);      // p0 x0 + p0 x1
+                        } else {
+                            static_assert(NA == 1 && NW == 2, "plane counts");
+                            wsacc[mt][dt] = mfma_bf(pair_(lh[0], lh[1]), xB[dt][0], wsacc[mt][dt]);      // (p0 + p1) x0
+                        }
+                    }
+                }
+            }
+            wave_sync();
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- outputs
+            if constexpr (PL != 0 && DT == 2) {
+                // plane image of the [rows, 2C] tensor [dX | dF]: a head's 32 channels are one 64-byte run per plane.  The lane
+                // pairs (kq, kq ^ 1) exchange one of their two 8-byte pieces (v_permlane16_swap) so that every lane stores 16
+                // contiguous bytes per plane: the 8-byte stores of the straight layout were issue-bound
+                const unsigned rowb = (row0 + pt) * (unsigned)((2 * Ctot / 32) * PL * 64);
+                const unsigned inrun = (kq & 1) ? 32u + 8u * (kq - 1) : 8u * kq;
+                const unsigned ox = pv ? rowb + (unsigned)(hh * PL * 64) + inrun : OOB_OFF;
+                const unsigned of_ = pv ? rowb + (unsigned)((Ctot / 32 + hh) * PL * 64) + inrun : OOB_OFF;
+                f32x2 xv[2][2], fv[2][2];            // [dt][pair]
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    xv[dt][0] = (f32x2){xacc[dt][0] * inv_tau, xacc[dt][1] * inv_tau};
+                    xv[dt][1] = (f32x2){xacc[dt][2] * inv_tau, xacc[dt][3] * inv_tau};
+                    fv[dt][0] = (f32x2){facc[dt][0], facc[dt][1]};
+                    fv[dt][1] = (f32x2){facc[dt][2], facc[dt][3]};
+                }
+                auto emit = [&](f32x2 (&v)[2][2], unsigned off) {
+#pragma unroll
+                    for (int q = 0; q < PL; ++q) {
+                        unsigned h[2][2];
+#pragma unroll
+                        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                            for (int k = 0; k < 2; ++k) {
+                                h[dt][k] = __builtin_bit_cast(unsigned, __builtin_convertvector(v[dt][k], bf16x2));
+                                if (q + 1 < PL)
+                                    v[dt][k] -= (f32x2){__uint_as_float(h[dt][k] << 16), __uint_as_float(h[dt][k] & 0xffff0000u)};
+                            }
+                        // even kq: (own dt 0, partner's dt 0); odd kq: (partner's dt 1, own dt 1)
+                        const auto s0 = __builtin_amdgcn_permlane16_swap(h[0][0], h[1][0], false, false);
+                        const auto s1 = __builtin_amdgcn_permlane16_swap(h[0][1], h[1][1], false, false);
+                        const u32x4 o = {s0[0], s1[0], s0[1], s1[1]};
+#ifdef S3B_NOSTORE
+                        if (o.x == 0x12345678u)
+#endif
+                        __builtin_amdgcn_raw_buffer_store_b128(o, rpl, off == OOB_OFF ? OOB_OFF : off + q * 64u, 0, 0);
+                    }
+                };
+                emit(xv, ox);
+                emit(fv, of_);
+            } else {
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const int d = 16 * dt + 4 * kq;
+                const bool ok = pv && d < D;
+                const float4 fo = make_float4(facc[dt][0], facc[dt][1], facc[dt][2], facc[dt][3]);
+                const float4 xo = make_float4(xacc[dt][0] * inv_tau, xacc[dt][1] * inv_tau, xacc[dt][2] * inv_tau,
+                                              xacc[dt][3] * inv_tau);
+                if constexpr (PL == 0) {
+                    Act<T>::bst4(rdf, ok ? (row0 + pt) * lddfb + hcol + d * ES : OOB_OFF, fo);
+                    Act<T>::bst4(rdx, ok ? (row0 + pt) * lddxb + hcol + d * ES : OOB_OFF, xo);
+                } else {
+                    // plane image of the [rows, 2C] tensor [dX | dF]: 4 consecutive channels = 8 bytes in each plane
+                    const int cx = hh * D + d, cf = Ctot + cx;
+                    const unsigned rowb = (row0 + pt) * (unsigned)((2 * Ctot / 32) * PL * 64);
+                    const unsigned ox = ok ? rowb + (unsigned)(((cx >> 5) * PL) * 64 + (cx & 31) * 2) : OOB_OFF;
+                    const unsigned of_ = ok ? rowb + (unsigned)(((cf >> 5) * PL) * 64 + (cf & 31) * 2) : OOB_OFF;
+                    f32x2 x01 = {xo.x, xo.y}, x23 = {xo.z, xo.w}, f01 = {fo.x, fo.y}, f23 = {fo.z, fo.w};
+#pragma unroll
+                    for (int q = 0; q < PL; ++q) {
+                        const unsigned hx0 = __builtin_bit_cast(unsigned, __builtin_convertvector(x01, bf16x2));
+                        const unsigned hx1 = __builtin_bit_cast(unsigned, __builtin_convertvector(x23, bf16x2));
+                        const unsigned hf0 = __builtin_bit_cast(unsigned, __builtin_convertvector(f01, bf16x2));
+                        const unsigned hf1 = __builtin_bit_cast(unsigned, __builtin_convertvector(f23, bf16x2));
+                        if (q + 1 < PL) {
+                            x01 -= (f32x2){__uint_as_float(hx0 << 16), __uint_as_float(hx0 & 0xffff0000u)};
+                            x23 -= (f32x2){__uint_as_float(hx1 << 16), __uint_as_float(hx1 & 0xffff0000u)};
+                            f01 -= (f32x2){__uint_as_float(hf0 << 16), __uint_as_float(hf0 & 0xffff0000u)};
+                            f23 -= (f32x2){__uint_as_float(hf1 << 16), __uint_as_float(hf1 & 0xffff0000u)};
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b64((u32x2){hx0, hx1}, rpl, ox == OOB_OFF ? OOB_OFF : ox + q * 64u, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b64((u32x2){hf0, hf1}, rpl, of_ == OOB_OFF ? OOB_OFF : of_ + q * 64u, 0, 0);
+                    }
+                }
+            }
+            }
+        }
+    }
+
+    // ---- block partials: dWs [M][D], dbs [M], dtau, (dbx | dbf) — waves add in fixed order
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dbacc[mt][r] = row16_sum(dbacc[mt][r]);
+    dtacc = wave_sum(dtacc);
+    float* const rW = reinterpret_cast<float*>(smem);      // aliases the images (dead after the point loop)
+    float* const rB = rW + 16 * MT * DP;
+    float* const rT = rB + 16 * MT;
+    static_assert((16 * MT * DP + 16 * MT + 4) * 4 <= C::IMGS, "reduction scratch must fit in the image region");
+    __syncthreads();
+    for (int wv = 0; wv < 4; ++wv) {
+        if (wave == wv) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = 16 * mt + 4 * kq + r;
+#pragma unroll
+                    for (int dt = 0; dt < DT; ++dt) {
+                        const int idx = m * DP + 16 * dt + li;
+                        rW[idx] = (wv == 0 ? 0.f : rW[idx]) + wsacc[mt][dt][r];
+                    }
+                    if (li == 0) rB[m] = (wv == 0 ? 0.f : rB[m]) + dbacc[mt][r];
+                }
+            if (lane == 0) rT[0] = (wv == 0 ? 0.f : rT[0]) + dtacc;
+        }
+        __syncthreads();
+    }
+    float* po = p.part + (size_t)bid * p.stride;
+    for (int i = tid; i < p.M * D; i += 256) po[i] = rW[(i / D) * DP + (i % D)] * inv_tau;
+    for (int i = tid; i < p.M; i += 256) po[p.M * D + i] = rB[i] * inv_tau;
+    if (tid == 0) po[p.M * D + p.M] = -rT[0] * inv_tau * inv_tau;
+    if constexpr (PL != 0) {
+        // conv bias gradients = column sums of dX | dF over the points, from token-level identities (no per-point sums):
+        //   sum_n dX[n][d] = sum_m (sum_n dL[n][m] / tau) Ws[m][d]     — this block's dbs partial
+        //   sum_n dF[n][d] = sum_m (sum_n W[n][m]) dS[m][d] = sum_m nrm[m] dS[m][d]   — whole (batch, head): chunk 0 only
+        for (int i = tid; i < 2 * D; i += 256) {
+            float v = 0.f;
+            if (i < D) {
+                for (int m = 0; m < p.M; ++m) v = fmaf(rB[m] * inv_tau, p.ws[(size_t)m * D + i], v);
+            } else if (chunk == 0) {
+                for (int m = 0; m < p.M; ++m) v = fmaf(p.nrm[bh * p.M + m], p.ds[(bh * p.M + m) * D + (i - D)], v);
+            }
+            po[p.M * D + p.M + 1 + i] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- host side
+template <int D, int MT, typename T, int PL>
+static int launch_bwd3_one(const SliceBwd3Params& p, int grid, hipStream_t st) {
+    constexpr int smem = BwCfg<D, MT>::SMEM;
+    if constexpr (smem > 160 * 1024) return PA2D_ERR_UNSUPPORTED;      // (D = 64, M = 128): the caller keeps the fp32-MFMA kernel
+    else {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&slice_bwd3_kernel<D, MT, T, PL>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((slice_bwd3_kernel<D, MT, T, PL>), dim3(slice_grid(grid)), dim3(256), smem, st, p);
+    return PA2D_OK;
+    }
+}
+template <int D, int MT>
+static int launch_bwd3_t(const SliceBwd3Params& p, int grid, hipStream_t st, bool bf, int planes_nt) {
+    if (planes_nt == 3) return bf ? PA2D_ERR_ARG : launch_bwd3_one<D, MT, float, 3>(p, grid, st);
+    if (planes_nt == 1) return bf ? PA2D_ERR_ARG : launch_bwd3_one<D, MT, float, 1>(p, grid, st);
+    return bf ? launch_bwd3_one<D, MT, bf16_t, 0>(p, grid, st) : launch_bwd3_one<D, MT, float, 0>(p, grid, st);
+}
+
+#define B3_DISPATCH_MT(D_, CALL)                                 \
+    switch (mt) {                                                \
+        case 1: CALL(D_, 1); break;                              \
+        case 2: CALL(D_, 2); break;                              \
+        case 4: CALL(D_, 4); break;                              \
+        case 8: CALL(D_, 8); break;                              \
+        default: return PA2D_ERR_UNSUPPORTED;                    \
+    }
+#define B3_DISPATCH_D(CALL)                                      \
+    switch (D) {                                                 \
+        case 8: B3_DISPATCH_MT(8, CALL) break;                   \
+        case 16: B3_DISPATCH_MT(16, CALL) break;                 \
+        case 32: B3_DISPATCH_MT(32, CALL) break;                 \
+        case 64: B3_DISPATCH_MT(64, CALL) break;                 \
+        default: return PA2D_ERR_UNSUPPORTED;                    \
+    }
+
+// called by pa2d_slice.hip with the fields of its SliceBwdParams; nchunk / ppc are the BACKWARD kernel's own chunking
+extern "C" __attribute__((visibility("hidden"))) int pa2d_launch_slice_bwd3(
+    const void* xm, long long ldx, const void* fm, long long ldf, const void* dy, long long lddy, const float* ws,
+    const float* bs, const float* temperature, const float* o, const float* ds, const float* dn, const float* nrm, void* dxm,
+    long long lddx, void* dfm, long long lddf, void* planes, unsigned planes_bytes, int planes_nt, int stride, float* part, int B, int N,
+    int heads, int D, int M, int mt, int nchunk, int ppc, unsigned x_bytes, unsigned f_bytes, unsigned dy_bytes,
+    unsigned dx_bytes, unsigned df_bytes, int clamp, int xcd_map, bool bf, hipStream_t st) {
+    SliceBwd3Params p;
+    p.xm = xm; p.ldx = ldx; p.fm = fm; p.ldf = ldf; p.dy = dy; p.lddy = lddy; p.ws = ws; p.bs = bs;
+    p.temperature = temperature; p.o = o; p.ds = ds; p.dn = dn; p.nrm = nrm; p.dxm = dxm; p.lddx = lddx; p.dfm = dfm; p.lddf = lddf;
+    p.planes = planes; p.planes_bytes = planes_bytes; p.stride = stride; p.part = part; p.B = B; p.N = N; p.heads = heads;
+    p.M = M; p.nchunk = nchunk; p.ppc = ppc; p.x_bytes = x_bytes; p.f_bytes = f_bytes; p.dy_bytes = dy_bytes;
+    p.dx_bytes = dx_bytes; p.df_bytes = df_bytes; p.clamp = clamp; p.xcd_map = xcd_map;
+    const int grid = B * heads * nchunk;
+    int rc = PA2D_OK;
+#define CALL_B3(D_, MT_) rc = launch_bwd3_t<D_, MT_>(p, grid, st, bf, planes_nt)
+    B3_DISPATCH_D(CALL_B3)
+    return rc;
+}

@@ -76,7 +76,7 @@ def attn_backward(saved, P, dout, H, W, heads, need_dx=True, engine=None, target
                                   want_norm=False, clamp=structured)
     ds, dn, dwq, dwk, dwv = ops.token_attn_bwd(s, nrm, P["wq"], P["wk"], P["wv"], dopart, into=t("wq", "wk", "wv"))
     if planes:
-        dxfp, dbx, dbf, dws, dbs, dtemp = ops.slice_bwd_points_planes(xf, dy, P["ws"], P["bs"], temp, o, ds, dn, B, N, heads,
+        dxfp, dbx, dbf, dws, dbs, dtemp = ops.slice_bwd_points_planes(xf, dy, P["ws"], P["bs"], temp, o, ds, dn, nrm, B, N, heads,
                                                                       D, M, engine, clamp=True,
                                                                       into=t("bx", "bf", "ws", "bs", "temperature"))
         dxn, dwx, dwf = ops.conv3x3x2_bwd_planes(dxfp, xn, P["wx"], P["wf"], B, H, W, engine, need_dx=need_dx,

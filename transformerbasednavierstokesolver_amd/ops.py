@@ -382,10 +382,11 @@ def conv3x3x2_bwd_planes(dout_planes, xn_planes, wx, wf, B, H, W, engine, need_d
     return dxn, dwx, dwf
 
 
-def slice_bwd_points_planes(xf, dy, ws_w, bs, temperature, o, ds, dn, B, N, heads, D, M, engine, clamp=True, into=None):
+def slice_bwd_points_planes(xf, dy, ws_w, bs, temperature, o, ds, dn, nrm, B, N, heads, D, M, engine, clamp=True, into=None):
     """slice_bwd_points whose [dX | dF] leaves only as the plane image for the conv backward; also returns the conv bias
-    gradients.  Returns (dxf_planes, dbx, dbf, dws, dbs, dtemperature); `into` = (dbx, dbf, dws, dbs, dtemperature)."""
-    _chk(xf, dy, ws_w, bs, temperature, o, ds, dn)
+    gradients (`nrm` = the forward's slice norms [B*heads, M], from token_attn_fwd).
+    Returns (dxf_planes, dbx, dbf, dws, dbs, dtemperature); `into` = (dbx, dbf, dws, dbs, dtemperature)."""
+    _chk(xf, dy, ws_w, bs, temperature, o, ds, dn, nrm)
     Cc = heads * D
     eng = _abi_engine(engine)
     planes = _planes(B * N, 2 * Cc, eng, xf)
@@ -394,7 +395,7 @@ def slice_bwd_points_planes(xf, dy, ws_w, bs, temperature, o, ds, dn, B, N, head
     ws = _ws(nb, xf)
     e0, e1 = _events("slice_bwd")
     _lib.check(_L().pa2d_slice_bwd_points_planes(_p(xf), 2 * Cc, _p(xf, Cc), 2 * Cc, _p(dy), Cc, _p(ws_w), _p(bs),
-                                                 _p(temperature), _p(o), _p(ds), _p(dn), planes.data_ptr(), _p(dbx), _p(dbf),
+                                                 _p(temperature), _p(o), _p(ds), _p(dn), _p(nrm), planes.data_ptr(), _p(dbx), _p(dbf),
                                                  _p(dws), _p(dbs), _p(dtemp), ws.data_ptr(), nb, B, N, heads, D, M,
                                                  int(clamp), acc, eng, _stream(), e0, e1), "slice_bwd_points_planes")
     return planes, dbx, dbf, dws, dbs, dtemp
