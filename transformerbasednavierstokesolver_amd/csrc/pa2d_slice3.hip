@@ -159,9 +159,9 @@ __device__ __forceinline__ void load_rawk(__amdgpu_buffer_rsrc_t r, unsigned off
     constexpr unsigned ES = Act<T>::ES;
     // pieces beyond D (D = 8 / 16: the second piece, and lane groups kq >= D / 4 of the first) must read zeros
     const int kq = (threadIdx.x >> 4) & 3;
-    const bool ok0 = 32 * s + 4 * kq < D, ok1 = 32 * s + 16 + 4 * kq < D;
+    const bool ok0 = D == 16 || 32 * s + 4 * kq < D, ok1 = D == 16 || 32 * s + 16 + 4 * kq < D;
     const unsigned o0 = (off != OOB_OFF && ok0) ? off + 32 * s * ES : OOB_OFF;
-    const unsigned o1 = (off != OOB_OFF && ok1) ? off + (32 * s + 16) * ES : OOB_OFF;
+    const unsigned o1 = (off != OOB_OFF && ok1) ? off + (D == 16 ? 4 : 32 * s + 16) * ES : OOB_OFF;   // D = 16: 8 adjacent d
     if constexpr (sizeof(T) == 2) {
         x.a = __builtin_amdgcn_raw_buffer_load_b64(r, o0, 0, 0);
         x.b = __builtin_amdgcn_raw_buffer_load_b64(r, o1, 0, 0);
@@ -192,6 +192,77 @@ __device__ __forceinline__ void load_par8(const float* mat, int m, int M, int s,
     }
     split8<3>(x, pl);
 }
+
+
+// ---- D = 16 (Darcy: 8 heads of 16 channels): a contraction over d fills only half of a 16x16x32 MFMA, so the other half of
+// the k index carries a second plane pair — the six terms of the 3 x 3 split are THREE MFMAs (fp32 storage; two for bf16
+// storage) instead of six half-empty ones, and every lane converts useful data.  k-slot (kq, j): plane pair member
+// "lo" at d = 8 kq + j for kq < 2, member "hi" at d = 8 (kq - 2) + j for kq >= 2:
+//   activations [x0|x1] [x0|x2] [x1|x0]  x  parameters [w0|w0] [w1|w0] [w1|w2]  =  w0x0 + w0x1, w1x0 + w0x2, w1x1 + w2x0.
+// The parameter planes live UNSCALED in LDS ([plane][slice][16 d], shared by the heads of the workgroup; log2(e)/tau is
+// applied inside exp2's fma), which also frees the 96 registers the M = 128 instantiations kept them in.
+template <int MT, typename T> struct W16 {
+    static constexpr int NA = Planes<T>::ACT, NC = NA == 3 ? 3 : 2, MP = 16 * MT, PIMG = MP * 32;
+    static constexpr int BIAS = 3 * PIMG, BYTES = BIAS + MP * 16;      // + bias as the MFMA C operand (fp32)
+    unsigned off[NC];
+    const unsigned char* img;
+    __device__ __forceinline__ void init(const unsigned char* base, int li, int kq) {
+        img = base;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const int pa = NA == 3 ? (c == 0 ? 0 : 1) : (c == 0 ? 0 : 2);
+            const int pb = NA == 3 ? (c == 2 ? 2 : 0) : (c == 0 ? 1 : 2);
+            off[c] = (unsigned)((kq < 2 ? pa : pb) * PIMG + li * 32 + (kq & 1) * 16);
+        }
+    }
+    __device__ __forceinline__ f32x4 bias_n(int mt, int li) const {      // N-layout: lane's slice 16 mt + li, all 4 rows
+        return *reinterpret_cast<const f32x4*>(img + BIAS + (16 * mt + li) * 16);
+    }
+    __device__ __forceinline__ f32x4 bias_t(int mt, int kq) const {      // T-layout: slices 16 mt + 4 kq .. + 3
+        return *reinterpret_cast<const f32x4*>(img + BIAS + (16 * mt + 4 * kq) * 4);
+    }
+    __device__ __forceinline__ bf16x8 frag(int c, int mt) const {
+        return *reinterpret_cast<const bf16x8*>(img + off[c] + mt * 512);
+    }
+    // every thread of the workgroup (before any wave leaves): split Ws [M][16] into the three plane images
+    // splat: bias[m] four times (N-layout logits: column = slice) or once (T-layout: rows = slices 4 kq + r)
+    static __device__ __forceinline__ void fill(unsigned char* base, const float* ws, const float* bs, int M, bool splat) {
+        for (int i = threadIdx.x; i < MP; i += blockDim.x) {
+            const float bv = i < M ? bs[i] : NEG_BIG;
+            if (splat) *reinterpret_cast<f32x4*>(base + BIAS + i * 16) = (f32x4){bv, bv, bv, bv};
+            else *reinterpret_cast<float*>(base + BIAS + i * 4) = bv;
+        }
+        for (int i = threadIdx.x; i < MP * 2; i += blockDim.x) {
+            const int m = i >> 1, d0 = 8 * (i & 1);
+            f32x8 v;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = m < M ? ws[(size_t)m * 16 + d0 + e] : 0.f;
+            bf16x8 pl[3];
+            split8<3>(v, pl);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) *reinterpret_cast<bf16x8*>(base + q * PIMG + m * 32 + d0 * 2) = pl[q];
+        }
+        __syncthreads();
+    }
+    // activation side of the K-packed terms
+    static __device__ __forceinline__ void combos(const bf16x8 (&xpl)[NA], int kq, bf16x8 (&xc)[NC]) {
+        const bool lo = kq < 2;
+        if constexpr (NA == 3) {
+            const u32x4 x0 = __builtin_bit_cast(u32x4, xpl[0]), x1 = __builtin_bit_cast(u32x4, xpl[1]),
+                        x2 = __builtin_bit_cast(u32x4, xpl[2]);
+            u32x4 c0, c1, c2;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { c0[i] = lo ? x0[i] : x1[i]; c1[i] = lo ? x0[i] : x2[i]; c2[i] = lo ? x1[i] : x0[i]; }
+            xc[0] = __builtin_bit_cast(bf16x8, c0); xc[1] = __builtin_bit_cast(bf16x8, c1); xc[2] = __builtin_bit_cast(bf16x8, c2);
+        } else {
+            const u32x4 x0 = __builtin_bit_cast(u32x4, xpl[0]);
+            u32x4 c1;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) c1[i] = lo ? x0[i] : 0u;
+            xc[0] = xpl[0]; xc[1] = __builtin_bit_cast(bf16x8, c1);      // [x0|x0] . [w0|w1], [x0|0] . [w2|-]
+        }
+    }
+};
 
 template <int D> struct BCfg {
     static constexpr int KST = (D + 31) / 32;      // 32-wide k-steps of a contraction over d
@@ -230,24 +301,33 @@ struct Scatter3Params {
 // kq) the 8 weights of points 4kq..4kq+3 and 16+4kq..16+4kq+3 = the A operand (rows = slices, k = points) of S += W^T V,
 // and the SAME lane holds the 8 normalisers 1/Z of exactly these points, which scale its 8 rows of V (B operand).
 template <int D, int MT, typename T>
-__global__ __launch_bounds__(MT <= 4 ? 512 : 256, MT <= 4 ? 2 : 1) void scatter3_kernel(const Scatter3Params p) {
+__global__ __launch_bounds__((MT <= 4 || D == 16) ? 512 : 256, (MT <= 4 || D == 16) ? 2 : 1) void scatter3_kernel(const Scatter3Params p) {
     constexpr int KST = BCfg<D>::KST, DT = BCfg<D>::DT;
     constexpr int NA = Planes<T>::ACT, NW = Planes<T>::WGT;
     constexpr unsigned ES = Act<T>::ES;
+    constexpr bool K16 = D == 16;
+    using W16T = W16<MT, T>;
+    __shared__ __attribute__((aligned(16))) unsigned char wimg[K16 ? W16T::BYTES : 16];
     const int lane = threadIdx.x & 63, li = lane & 15, kq = lane >> 4;
+    if constexpr (K16) W16T::fill(wimg, p.ws, p.bs, p.M, true);
     int b, hh, chunk, bid;
     if (!slice3_decode(p.B, p.heads, p.nchunk, b, hh, chunk, bid)) return;
     const float scale = LOG2E / (p.clamp ? clamp_tau(p.temperature[hh]) : p.temperature[hh]);
+    const float esc = K16 ? scale : 1.0f;      // generic: Ws and bs are pre-scaled;  D = 16: applied inside exp2's fma
 
-    bf16x8 wsp[MT][KST][3];      // B operand of the logits: column = slice 16mt+li, k = d
-    f32x4 bias[MT];              // C operand of the first MFMA of a logits chain
+    bf16x8 wsp[K16 ? 1 : MT][KST][3];      // B operand of the logits: column = slice 16mt+li, k = d
+    W16T w16;
+    if constexpr (K16) w16.init(wimg, li, kq);
+    f32x4 bias[K16 ? 1 : MT];    // C operand of the first MFMA of a logits chain (D = 16: read from LDS)
+    if constexpr (!K16) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
-        const int m = 16 * mt + li;
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = 16 * mt + li;
 #pragma unroll
-        for (int s = 0; s < KST; ++s) load_par8<D>(p.ws, m, p.M, s, kq, scale, wsp[mt][s]);
-        const float bv = m < p.M ? p.bs[m] * scale : NEG_BIG;
-        bias[mt] = (f32x4){bv, bv, bv, bv};
+            for (int s = 0; s < KST; ++s) load_par8<D>(p.ws, m, p.M, s, kq, scale, wsp[mt][s]);
+            const float bv = m < p.M ? p.bs[m] * scale : NEG_BIG;
+            bias[mt] = (f32x4){bv, bv, bv, bv};
+        }
     }
     f32x4 sacc[MT][DT];
     float nacc[MT];
@@ -270,7 +350,7 @@ __global__ __launch_bounds__(MT <= 4 ? 512 : 256, MT <= 4 ? 2 : 1) void scatter3
     // group, one dword each: the row offsets e * ldv are wave-uniform (scalar offsets of the loads).
     unsigned xo[2], vo = (row0 + 4 * kq) * ldvb + hcol + li * ES;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) xo[t] = (row0 + 16 * t + li) * ldxb + hcol + 4 * kq * ES;
+    for (int t = 0; t < 2; ++t) xo[t] = (row0 + 16 * t + li) * ldxb + hcol + (K16 ? 8 * (kq & 1) : 4 * kq) * ES;
     const unsigned xstep = 32u * ldxb, vstep = 32u * ldvb;
     unsigned vrow[8];
 #pragma unroll
@@ -300,29 +380,6 @@ __global__ __launch_bounds__(MT <= 4 ? 512 : 256, MT <= 4 ? 2 : 1) void scatter3
     };
     auto group = [&](auto tail, int n_left, int n_next) {        // n_left: points left in the chunk from this group on
         constexpr bool TAIL = decltype(tail)::value;
-#ifdef S3_LOADS_ONLY
-        {
-#pragma unroll
-            for (int t = 0; t < 2; ++t)
-#pragma unroll
-                for (int s = 0; s < KST; ++s) {
-                    bf16x8 xpl[NA];
-                    rawk_planes<T>(xr[t][s], xpl);
-                    sacc[0][0] = mfma_bf(xpl[0], xpl[0], sacc[0][0]);
-                }
-            xo[0] += xstep; xo[1] += xstep;
-            if (n_next >= 32) load_x(std::false_type{}, n_next);
-            else if (n_next > 0) load_x(std::true_type{}, n_next);
-#pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) sacc[0][dt][e & 3] += fv[dt][e];
-            vo += vstep;
-            if (n_next >= 32) load_v(std::false_type{}, n_next);
-            else if (n_next > 0) load_v(std::true_type{}, n_next);
-            return;
-        }
-#endif
         f32x4 w[2][MT];          // logits, then unnormalised weights exp2(z - max)
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -330,14 +387,24 @@ __global__ __launch_bounds__(MT <= 4 ? 512 : 256, MT <= 4 ? 2 : 1) void scatter3
             for (int s = 0; s < KST; ++s) {
                 bf16x8 xpl[NA];
                 rawk_planes<T>(xr[t][s], xpl);
+                if constexpr (K16) {
+                    bf16x8 xc[W16T::NC];
+                    W16T::combos(xpl, kq, xc);
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) w[t][mt] = mfma_terms<NA, 3>(xpl, wsp[mt][s], s == 0 ? bias[mt] : w[t][mt]);
+                    for (int mt = 0; mt < MT; ++mt) {
+                        f32x4 a = w16.bias_n(mt, li);
+#pragma unroll
+                        for (int c = W16T::NC - 1; c >= 0; --c) a = mfma_bf(xc[c], w16.frag(c, mt), a);
+                        w[t][mt] = a;
+                    }
+                } else {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) w[t][mt] = mfma_terms<NA, 3>(xpl, wsp[mt][s], s == 0 ? bias[mt] : w[t][mt]);
+                }
             }
         xo[0] += xstep; xo[1] += xstep;
-#ifndef S3_COMPUTE_ONLY
         if (n_next >= 32) load_x(std::false_type{}, n_next);
         else if (n_next > 0) load_x(std::true_type{}, n_next);
-#endif
         f32x4 inv[2];
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
@@ -353,9 +420,10 @@ __global__ __launch_bounds__(MT <= 4 ? 512 : 256, MT <= 4 ? 2 : 1) void scatter3
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 sm[r] = 0.f;
+                const float nm = -mx[r] * esc;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
-                    const float e = ex2(w[t][mt][r] - mx[r]);
+                    const float e = K16 ? ex2(fmaf(w[t][mt][r], esc, nm)) : ex2(w[t][mt][r] - mx[r]);
                     w[t][mt][r] = e;
                     sm[r] += e;
                 }
@@ -385,10 +453,8 @@ __global__ __launch_bounds__(MT <= 4 ? 512 : 256, MT <= 4 ? 2 : 1) void scatter3
             split8<NA>(f, fp[dt]);          // bf16 storage: the values ARE one plane (exact)
         }
         vo += vstep;
-#ifndef S3_COMPUTE_ONLY
         if (n_next >= 32) load_v(std::false_type{}, n_next);
         else if (n_next > 0) load_v(std::true_type{}, n_next);
-#endif
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             f32x8 wv;
@@ -444,28 +510,37 @@ struct Deslice3Params {
 // point for the slices 16mt + 4kq + r, i.e. the B operand (k = slices, columns = points) of Y^T = O^T W^T; softmax is
 // in-lane plus the two row swaps, and the normalisation 1/Z multiplies the D outputs of the point.
 template <int D, int MT, typename T>
-__global__ __launch_bounds__(MT <= 4 ? 512 : 256, MT <= 4 ? 2 : 1) void deslice3_kernel(const Deslice3Params p) {
+__global__ __launch_bounds__((MT <= 4 || D == 16) ? 512 : 256, (MT <= 4 || D == 16) ? 2 : 1) void deslice3_kernel(const Deslice3Params p) {
     constexpr int KST = BCfg<D>::KST, DT = BCfg<D>::DT;
     constexpr int NA = Planes<T>::ACT, NW = Planes<T>::WGT;
     constexpr int MU = (MT + 1) / 2;                 // 32-slice k-steps of the contraction over m
     constexpr unsigned ES = Act<T>::ES;
+    constexpr bool K16 = D == 16;
+    using W16T = W16<MT, T>;
+    __shared__ __attribute__((aligned(16))) unsigned char wimg[K16 ? W16T::BYTES : 16];
     const int lane = threadIdx.x & 63, li = lane & 15, kq = lane >> 4;
+    if constexpr (K16) W16T::fill(wimg, p.ws, p.bs, p.M, false);
     int b, hh, chunk, bid;
     if (!slice3_decode(p.B, p.heads, p.nchunk, b, hh, chunk, bid)) return;
     const float scale = LOG2E / (p.clamp ? clamp_tau(p.temperature[hh]) : p.temperature[hh]);
+    const float esc = K16 ? scale : 1.0f;
 
-    bf16x8 wsp[MT][KST][3];      // A operand of the transposed logits: row = slice 16mt+li, k = d
-    f32x4 bias[MT];              // C operand: rows = slices 16mt + 4kq + r
+    bf16x8 wsp[K16 ? 1 : MT][KST][3];      // A operand of the transposed logits: row = slice 16mt+li, k = d
+    W16T w16;
+    if constexpr (K16) w16.init(wimg, li, kq);
+    f32x4 bias[K16 ? 1 : MT];    // C operand: rows = slices 16mt + 4kq + r (D = 16: read from LDS)
     bf16x8 op[MU][DT][3];        // A operand of Y^T = O^T W^T: row = channel 16dt+li, k = slices of k-step u
     const float* ob = p.o + (size_t)(b * p.heads + hh) * p.M * D;
+    if constexpr (!K16) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
-        for (int s = 0; s < KST; ++s) load_par8<D>(p.ws, 16 * mt + li, p.M, s, kq, scale, wsp[mt][s]);
+            for (int s = 0; s < KST; ++s) load_par8<D>(p.ws, 16 * mt + li, p.M, s, kq, scale, wsp[mt][s]);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int mr = 16 * mt + 4 * kq + r;
-            bias[mt][r] = mr < p.M ? p.bs[mr] * scale : NEG_BIG;
+            for (int r = 0; r < 4; ++r) {
+                const int mr = 16 * mt + 4 * kq + r;
+                bias[mt][r] = mr < p.M ? p.bs[mr] * scale : NEG_BIG;
+            }
         }
     }
 #pragma unroll
@@ -490,7 +565,7 @@ __global__ __launch_bounds__(MT <= 4 ? 512 : 256, MT <= 4 ? 2 : 1) void deslice3
     unsigned xo[2], yo[2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-        xo[t] = (row0 + 16 * t + li) * ldxb + hcol + 4 * kq * ES;
+        xo[t] = (row0 + 16 * t + li) * ldxb + hcol + (K16 ? 8 * (kq & 1) : 4 * kq) * ES;
         yo[t] = (row0 + 16 * t + li) * ldyb + hcol + 4 * kq * ES;
     }
     const unsigned xstep = 32u * ldxb, ystep = 32u * ldyb;
@@ -513,8 +588,20 @@ __global__ __launch_bounds__(MT <= 4 ? 512 : 256, MT <= 4 ? 2 : 1) void deslice3
             for (int s = 0; s < KST; ++s) {
                 bf16x8 xpl[NA];
                 rawk_planes<T>(xr[t][s], xpl);
+                if constexpr (K16) {
+                    bf16x8 xc[W16T::NC];
+                    W16T::combos(xpl, kq, xc);
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) w[t][mt] = mfma_terms<3, NA>(wsp[mt][s], xpl, s == 0 ? bias[mt] : w[t][mt]);
+                    for (int mt = 0; mt < MT; ++mt) {
+                        f32x4 a = w16.bias_t(mt, kq);
+#pragma unroll
+                        for (int c = W16T::NC - 1; c >= 0; --c) a = mfma_bf(w16.frag(c, mt), xc[c], a);
+                        w[t][mt] = a;
+                    }
+                } else {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) w[t][mt] = mfma_terms<3, NA>(wsp[mt][s], xpl, s == 0 ? bias[mt] : w[t][mt]);
+                }
             }
         xo[0] += xstep; xo[1] += xstep;
         if (n_next >= 32) load_x(std::false_type{}, n_next);
@@ -528,11 +615,12 @@ __global__ __launch_bounds__(MT <= 4 ? 512 : 256, MT <= 4 ? 2 : 1) void deslice3
                 for (int r = 0; r < 4; ++r) mx = fmaxf(mx, w[t][mt][r]);
             mx = kq_max(mx);
             float sm = 0.f;
+            const float nm = -mx * esc;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float e = ex2(w[t][mt][r] - mx);
+                    const float e = K16 ? ex2(fmaf(w[t][mt][r], esc, nm)) : ex2(w[t][mt][r] - mx);
                     w[t][mt][r] = e;
                     sm += e;
                 }
@@ -579,6 +667,14 @@ __global__ __launch_bounds__(MT <= 4 ? 512 : 256, MT <= 4 ? 2 : 1) void deslice3
 }
 
 // ---------------------------------------------------------------------------------------------- host side
+// heads per workgroup: up to 8 waves (4 for the 256-register M = 128 instantiations) that read neighbouring head segments
+// of the same rows; small problems (rollout at batch 1) keep fewer heads per workgroup so that every CU gets a wave
+static int slice3_hpw(int B, int heads, int nchunk, int mt, int D) {
+    int hpw = (mt <= 4 || D == 16) ? 8 : 4;
+    if (hpw > heads) hpw = heads;
+    while (hpw > 1 && (long long)B * nchunk * ((heads + hpw - 1) / hpw) < 256) hpw >>= 1;
+    return hpw;
+}
 #define S3_DISPATCH_MT(D_, CALL)                                 \
     switch (mt) {                                                \
         case 1: CALL(D_, 1); break;                              \
@@ -604,7 +700,7 @@ extern "C" __attribute__((visibility("hidden"))) int pa2d_launch_scatter3(const 
     p.xm = xm; p.ldx = ldx; p.v = v; p.ldv = ldv; p.ws = ws; p.bs = bs; p.temperature = temperature;
     p.spart = spart; p.npart = npart; p.B = B; p.N = N; p.heads = heads; p.M = M; p.nchunk = nchunk; p.ppc = ppc;
     p.x_bytes = x_bytes; p.v_bytes = v_bytes; p.clamp = clamp; p.xcd_map = xcd_map;
-    const int hmax = mt <= 4 ? 8 : 4, hpw = heads < hmax ? heads : hmax;
+    const int hpw = slice3_hpw(B, heads, nchunk, mt, D);
     const dim3 grid(B * nchunk * ((heads + hpw - 1) / hpw)), block(64 * hpw);
 #define CALL_S3(D_, MT_)                                                                                          \
     if (bf) hipLaunchKernelGGL((scatter3_kernel<D_, MT_, bf16_t>), grid, block, 0, st, p);                        \
@@ -620,7 +716,7 @@ extern "C" __attribute__((visibility("hidden"))) int pa2d_launch_deslice3(const 
     p.xm = xm; p.ldx = ldx; p.o = o; p.ws = ws; p.bs = bs; p.temperature = temperature; p.y = y; p.ldy = ldy;
     p.B = B; p.N = N; p.heads = heads; p.M = M; p.nchunk = nchunk; p.ppc = ppc; p.x_bytes = x_bytes; p.y_bytes = y_bytes;
     p.clamp = clamp;
-    const int hmax = mt <= 4 ? 8 : 4, hpw = heads < hmax ? heads : hmax;
+    const int hpw = slice3_hpw(B, heads, nchunk, mt, D);
     const dim3 grid(B * nchunk * ((heads + hpw - 1) / hpw)), block(64 * hpw);
 #define CALL_D3(D_, MT_)                                                                                          \
     if (bf) hipLaunchKernelGGL((deslice3_kernel<D_, MT_, bf16_t>), grid, block, 0, st, p);                        \
