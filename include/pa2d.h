@@ -54,6 +54,10 @@ const char* pa2d_version(void);
  * PA2D_ENGINE_SPLIT.  It only reads the environment; no entry point consults it implicitly. */
 enum pa2d_engine { PA2D_ENGINE_F32 = 0, PA2D_ENGINE_SPLIT = 1, PA2D_ENGINE_BF16 = 2 };
 int pa2d_default_engine(void);
+/* Kernel-selection overrides (PA2D_CONV_HALO, PA2D_MC_BIG, PA2D_LIN_PANEL, ...: A/B timing and the parity tests that
+ * force one of two equivalent kernels) and PA2D_GEMM are read from the environment ONCE, when the library is loaded;
+ * pa2d_reload_env() reads them again (tests).  They never change the numerics contract of an entry point. */
+void pa2d_reload_env(void);
 
 /* ---- LayerNorm: nn.LayerNorm(C) of Transolver_block, model/Transolver_Structured_Mesh_2D.py:58,62,65,70-73 */
 int pa2d_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* mean,
@@ -114,12 +118,15 @@ int pa2d_conv3x3x2_bwd(const float* dout, const float* xn, const float* wx, cons
  * pa2d_slice_nchunk(B,N,heads); `v` is fx_mid in the forward and dY in backward phase A.
  * D in {8,16,32,64}, M <= 128.  clamp_temperature: 1 = clamp(temperature, 0.1, 5) as the structured-mesh
  * attention does (Physics_Attention.py:98-99); 0 = raw temperature (irregular mesh, :40).
+ * `engine` (here, on de-slice and on the slice backward): PA2D_ENGINE_F32 = every contraction on the exact-fp32 matrix
+ * instruction (v_mfma_f32_16x16x4_f32); PA2D_ENGINE_SPLIT / _BF16 = bf16 MFMA on exact 3-plane operand splits with fp32
+ * accumulation (24-bit significand; the same parity tolerances).  The bf16-storage variants below have no such argument.
  * ev_start / ev_stop (here and on de-slice / slice backward): optional hipEvent_t recorded on `stream` right around
  * the point kernel, as for the conv. */
 int pa2d_slice_nchunk(int B, int N, int heads);
 int pa2d_slice_scatter(const float* xm, long long ldx, const float* v, long long ldv, const float* ws,
                        const float* bs, const float* temperature, float* spart, float* npart, int B, int N,
-                       int heads, int D, int M, int clamp_temperature, pa2d_stream_t stream, void* ev_start,
+                       int heads, int D, int M, int clamp_temperature, int engine, pa2d_stream_t stream, void* ev_start,
                        void* ev_stop);
 
 /* ---- token attention among the M slice tokens of each (batch, head): normalisation by
@@ -138,7 +145,7 @@ int pa2d_token_attn_bwd(const float* s, const float* nrm, const float* wq, const
  * (Physics_Attention.py:116-117); slice weights are recomputed from x_mid, never stored. */
 int pa2d_deslice_fwd(const float* xm, long long ldx, const float* o, const float* ws, const float* bs,
                      const float* temperature, float* y, long long ldy, int B, int N, int heads, int D, int M,
-                     int clamp_temperature, pa2d_stream_t stream, void* ev_start, void* ev_stop);
+                     int clamp_temperature, int engine, pa2d_stream_t stream, void* ev_start, void* ev_stop);
 
 /* ---- backward of slice + de-slice w.r.t. the points (autograd of
  * Physics_Attention.py:98-101,116): given dY, O, dS, dn produces dx_mid, dfx_mid and the fully
@@ -149,7 +156,7 @@ int pa2d_slice_bwd_points(const float* xm, long long ldx, const float* fm, long 
                           const float* o, const float* ds, const float* dn, float* dxm, long long lddx,
                           float* dfm, long long lddf, float* dws, float* dbs, float* dtemperature, void* ws_buf,
                           size_t ws_bytes, int B, int N, int heads, int D, int M, int clamp_temperature,
-                          int accumulate, pa2d_stream_t stream, void* ev_start, void* ev_stop);
+                          int accumulate, int engine, pa2d_stream_t stream, void* ev_start, void* ev_stop);
 
 /* ---- output head mlp2 = nn.Linear(C, out_dim), out_dim <= 8 (…_2D.py:66,73) */
 int pa2d_head_fwd(const float* xn, const float* w, const float* b, float* y, int rows, int C, int out_dim,

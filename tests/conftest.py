@@ -28,3 +28,22 @@ def rel_l2(a, b):
     a = torch.as_tensor(a).detach().double().cpu()
     b = torch.as_tensor(b).detach().double().cpu()
     return float((a - b).norm() / b.norm().clamp_min(1e-300))
+
+
+@pytest.fixture
+def kernel_env(monkeypatch):
+    """Set kernel-selection overrides (PA2D_CONV_HALO, PA2D_MC_BIG, ...) for one test: libpa2d reads them once at load, so
+    the table is re-read after every change and once more when the test's environment has been restored."""
+    from transformerbasednavierstokesolver_amd import _lib
+
+    def set_(**kv):
+        for k, v in kv.items():
+            if v is None:
+                monkeypatch.delenv(k, raising=False)
+            else:
+                monkeypatch.setenv(k, v)
+        _lib.load().pa2d_reload_env()
+
+    yield set_
+    monkeypatch.undo()
+    _lib.load().pa2d_reload_env()

@@ -80,12 +80,12 @@ def test_linear_bf16(M, N, K, act):
 
 @pytest.mark.parametrize("policy", ["force", "off"])
 @pytest.mark.parametrize("B,H,W,C", [(2, 64, 64, 256), (1, 21, 17, 128), (2, 16, 16, 32), (1, 12, 20, 192)])
-def test_conv_bf16(monkeypatch, B, H, W, C, policy):
+def test_conv_bf16(kernel_env, B, H, W, C, policy):
     """both conv kernels (halo tile in LDS / plain implicit GEMM) with bf16 in, bf16 out; weight gradient straight from
     the bf16 tensors (they ARE the 1-plane operand images), fp32 out"""
     from transformerbasednavierstokesolver_amd import ops
     from oracle import transolver_oracle as orc
-    monkeypatch.setenv("PA2D_CONV_HALO", policy)
+    kernel_env(PA2D_CONV_HALO=policy)
     rng = np.random.default_rng(B * H + C)
     N = H * W
     (xn, xnd), (dout, doutd) = _b(_r(rng, B, N, C)), _b(_r(rng, B, N, 2 * C))

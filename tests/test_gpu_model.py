@@ -423,7 +423,11 @@ def test_c_abi_error_codes_on_device():
     # more slices than the token kernel holds -> UNSUPPORTED
     assert L.pa2d_token_attn_fwd(ptr, ptr, ptr, ptr, ptr, ptr, ptr, ptr, 1, 1, 129, 8, st) == 1002
     # head dim outside {8,16,32,64} -> ARG/UNSUPPORTED
-    assert L.pa2d_slice_scatter(ptr, 12, ptr, 12, ptr, ptr, ptr, ptr, ptr, 1, 16, 1, 12, 8, 1, st, 0, 0) in (1001, 1002)
+    for engine in (0, 1):
+        assert L.pa2d_slice_scatter(ptr, 12, ptr, 12, ptr, ptr, ptr, ptr, ptr, 1, 16, 1, 12, 8, 1, engine, st, 0, 0) in (1001, 1002)
+    # unknown slice engine id -> ARG
+    assert L.pa2d_slice_scatter(ptr, 16, ptr, 16, ptr, ptr, ptr, ptr, ptr, 1, 16, 1, 16, 8, 1, 5, st, 0, 0) == 1001
+    assert L.pa2d_deslice_fwd(ptr, 16, ptr, ptr, ptr, ptr, ptr, 16, 1, 16, 1, 16, 8, 1, -1, st, 0, 0) == 1001
     # workspace too small -> WORKSPACE
     assert L.pa2d_gemm_bwd_weight(ptr, 8, ptr, 8, ptr, ptr, ptr, 16, 64, 8, 8, 0, 0, st) == 1003
     for engine in (0, 1, 2):

@@ -146,8 +146,9 @@ def _slice_inputs(B, N, heads, D, M, seed):
     return xf, ws, bs, temp, wq, wk, wv, dy
 
 
+@pytest.mark.parametrize("engine", ENGINES)       # f32: exact v_mfma_f32_16x16x4_f32 kernels; split: bf16 MFMA on exact 3-plane splits
 @pytest.mark.parametrize("B,N,heads,D,M", SLICE_CASES)
-def test_slice_token_deslice_forward(dev, B, N, heads, D, M):
+def test_slice_token_deslice_forward(dev, B, N, heads, D, M, engine):
     from transformerbasednavierstokesolver_amd import ops
     from oracle import transolver_oracle as orc
     C = heads * D
@@ -157,7 +158,7 @@ def test_slice_token_deslice_forward(dev, B, N, heads, D, M):
     o = orc.token_attention(tok, wq.double(), wk.double(), wv.double())
     y = orc.deslice(w, o)
     g = lambda t: t.to(dev)
-    spart, npart = ops.slice_scatter(g(xf), 2 * C, 0, g(xf), 2 * C, C, g(ws), g(bs), g(temp), B, N, heads, D, M)
+    spart, npart = ops.slice_scatter(g(xf), 2 * C, 0, g(xf), 2 * C, C, g(ws), g(bs), g(temp), B, N, heads, D, M, engine=engine)
     assert rel_l2(spart.sum(1).view(B, heads, M, D), s) < FWD_TOL
     assert rel_l2(npart.sum(1).view(B, heads, M), norm) < FWD_TOL
     sk, nk, ok = ops.token_attn_fwd(spart, npart, g(wq), g(wk), g(wv))
@@ -165,12 +166,13 @@ def test_slice_token_deslice_forward(dev, B, N, heads, D, M):
     assert rel_l2(ok.view(B, heads, M, D), o) < 2e-5
     # de-slice checked with the ORACLE's tokens so that errors do not compound
     yk = ops.deslice_fwd(g(xf), 2 * C, 0, g(o.float().reshape(B * heads, M, D).contiguous()), g(ws), g(bs), g(temp),
-                         B, N, heads, D, M)
+                         B, N, heads, D, M, engine=engine)
     assert rel_l2(yk, y) < FWD_TOL
 
 
+@pytest.mark.parametrize("engine", ENGINES)
 @pytest.mark.parametrize("B,N,heads,D,M", SLICE_CASES)
-def test_slice_core_backward(dev, B, N, heads, D, M):
+def test_slice_core_backward(dev, B, N, heads, D, M, engine):
     from transformerbasednavierstokesolver_amd import ops
     from oracle import transolver_oracle as orc
     C = heads * D
@@ -179,10 +181,11 @@ def test_slice_core_backward(dev, B, N, heads, D, M):
     ref = orc.slice_core_backward(d(xf[..., :C]), d(xf[..., C:]), d(dy), d(ws), d(bs), d(temp), d(wq), d(wk), d(wv), heads)
     g = lambda t: t.to(dev).contiguous()
     # forward state
-    spart, npart = ops.slice_scatter(g(xf), 2 * C, 0, g(xf), 2 * C, C, g(ws), g(bs), g(temp), B, N, heads, D, M)
+    spart, npart = ops.slice_scatter(g(xf), 2 * C, 0, g(xf), 2 * C, C, g(ws), g(bs), g(temp), B, N, heads, D, M, engine=engine)
     s, nrm, o = ops.token_attn_fwd(spart, npart, g(wq), g(wk), g(wv))
     # phase A: dO partials
-    dopart, _ = ops.slice_scatter(g(xf), 2 * C, 0, g(dy), C, 0, g(ws), g(bs), g(temp), B, N, heads, D, M, want_norm=False)
+    dopart, _ = ops.slice_scatter(g(xf), 2 * C, 0, g(dy), C, 0, g(ws), g(bs), g(temp), B, N, heads, D, M, want_norm=False,
+                                  engine=engine)
     assert rel_l2(dopart.sum(1).view(B, heads, M, D), ref["do"]) < BWD_TOL
     ds, dn, dwq, dwk, dwv = ops.token_attn_bwd(s, nrm, g(wq), g(wk), g(wv), dopart)
     assert rel_l2(ds.view(B, heads, M, D), ref["ds"]) < 5e-5
@@ -194,7 +197,7 @@ def test_slice_core_backward(dev, B, N, heads, D, M):
                                 d(wq), d(wk), d(wv))
     dxf, dws, dbs, dtemp = ops.slice_bwd_points(g(xf), g(dy), g(ws), g(bs), g(temp), f32(o_ref, B * heads, M, D),
                                                 f32(ref["ds"], B * heads, M, D), f32(ref["dn"], B * heads, M),
-                                                B, N, heads, D, M)
+                                                B, N, heads, D, M, engine=engine)
     assert rel_l2(dxf[..., :C], ref["dxm"]) < BWD_TOL
     assert rel_l2(dxf[..., C:], ref["dfm"]) < BWD_TOL
     assert rel_l2(dws, ref["dws"]) < BWD_TOL and rel_l2(dbs, ref["dbs"]) < BWD_TOL
@@ -221,23 +224,21 @@ def test_head(dev, rows, C, O):
 @pytest.mark.parametrize("policy", ["force", "off"])
 @pytest.mark.parametrize("B,H,W,C", [(2, 64, 64, 256), (1, 21, 17, 128), (2, 16, 16, 64), (1, 12, 20, 192), (3, 8, 32, 32),
                                      (1, 45, 70, 64), (2, 24, 24, 192), (1, 40, 30, 128)])
-def test_conv_split_engine_both_kernels(dev, monkeypatch, B, H, W, C, policy):
+def test_conv_split_engine_both_kernels(dev, kernel_env, B, H, W, C, policy):
     """The split engine has two conv kernels: the halo-tile-in-LDS kernel (spatial 8x32 tiles; picked when the launch
     fills the chip) and the plain implicit-GEMM kernel.  PA2D_CONV_HALO forces either one on shapes with ragged
     tiles in both directions, several images and 1..8 channel chunks: same fp32 tolerances.  Likewise the weight
     gradient: 256x256-tile planes kernel (default when 2C >= 256; the last two shapes have ragged row AND column
     tiles and column groups whose taps change inside a tile) vs the 128x128 one (PA2D_MC_BIG=off)."""
-    monkeypatch.setenv("PA2D_CONV_HALO", policy)
-    if policy == "off":
-        monkeypatch.setenv("PA2D_MC_BIG", "off")
+    kernel_env(PA2D_CONV_HALO=policy, PA2D_MC_BIG="off" if policy == "off" else None)
     _check_conv(dev, B, H, W, C, "split", FWD_TOL, BWD_TOL)
 
 
-def test_bf16_compute_engine_stage_tolerances(dev, monkeypatch):
-    monkeypatch.setenv("PA2D_CONV_HALO", "force")
+def test_bf16_compute_engine_stage_tolerances(dev, kernel_env):
+    kernel_env(PA2D_CONV_HALO="force")
     _check_conv(dev, 2, 64, 64, 256, "bf16", 1e-2, 1e-2)
     _check_conv(dev, 1, 21, 17, 128, "bf16", 1e-2, 1e-2)
-    monkeypatch.delenv("PA2D_CONV_HALO")
+    kernel_env(PA2D_CONV_HALO=None)
     _bf16_stage_cases(dev)
 
 
@@ -375,6 +376,96 @@ def test_split_engine_adversarial_operands_linear(dev):
     assert torch.equal(masks["f32"], masks["split"])
     bad = (~masks["split"]).any(-1)
     assert bad.nonzero().flatten().tolist() == [5, 40000, 65535] and bool((~masks["split"])[5].all())
+
+
+def test_split_engine_adversarial_operands_slice(dev):
+    """The slice stages on the bf16-split kernels (engine "split": logits, scatter, gather and every backward contraction as
+    six bf16 MFMA terms of exact 3-plane splits) against the exact-fp32-MFMA kernels (engine "f32") on operands that never
+    passed a LayerNorm: x_mid / fx_mid are conv outputs and the logits are divided by a temperature clamped down to 0.1
+    (Physics_Attention.py:98-99).  Conditions: per-point dynamic range 2^+-40, raw temperatures at and beyond both clamp
+    ends, logits whose spread (+-300) overflows exp without the max subtraction, exact zeros, +-inf / NaN rows.  Asserted
+    against fp64: split error <= 2 x exact error (+ the fp32 rounding floor), identical non-finite masks."""
+    from transformerbasednavierstokesolver_amd import ops
+    from oracle import transolver_oracle as orc
+    B, N, heads, D, M = 2, 700, 8, 32, 64
+    C = heads * D
+    rng = np.random.default_rng(4242)
+    g = lambda t: t.to(dev).contiguous()
+    ws, bs = _r(rng, M, D, scale=D ** -0.5), 0.3 * _r(rng, M)
+    wq, wk, wv = (_r(rng, D, D, scale=1.5 * D ** -0.5) for _ in range(3))
+    temp = torch.tensor([0.1, 5.0, 0.01, 50.0, 0.5, 0.1000001, 4.9999995, 1.0])      # both clamp ends, inside and outside
+    base = _r(rng, B, N, 2 * C)
+
+    def run(xf, engine):
+        spart, npart = ops.slice_scatter(g(xf), 2 * C, 0, g(xf), 2 * C, C, g(ws), g(bs), g(temp), B, N, heads, D, M, engine=engine)
+        s, nrm = spart.sum(1).view(B, heads, M, D), npart.sum(1).view(B, heads, M)
+        return s, nrm
+
+    def run_y(xf, o, engine):
+        return ops.deslice_fwd(g(xf), 2 * C, 0, g(o.float().reshape(B * heads, M, D).contiguous()), g(ws), g(bs), g(temp),
+                               B, N, heads, D, M, engine=engine)
+
+    def ref(xf):
+        xd = xf.double()
+        w, norm, s, tok = orc.slice_tokens(xd[..., :C], xd[..., C:], ws.double(), bs.double(), temp.double(), heads)
+        o = orc.token_attention(tok, wq.double(), wk.double(), wv.double())
+        return s, norm, o, orc.deslice(w, o)
+
+    def err(a, r):
+        a, r = a.double().cpu(), r.double().cpu()
+        sc = 2.0 ** -round(float(torch.log2(r.abs().max().clamp_min(1e-300))))      # keep the norms inside fp64
+        return float(((a - r) * sc).norm() / (r * sc).norm())
+
+    scale = torch.from_numpy(np.exp2(rng.uniform(-40, 40, size=(B, N, 1))).astype(np.float32))
+    spread = base.clone()
+    spread[..., :C] *= 60.0                      # logits ~ 60 / 0.1: +-300 and more, far beyond exp's fp32 range
+    zeros = base.clone()
+    zeros[:, ::3] = 0.0                          # every third point: uniform weights, zero values
+    zeros[..., 5] = 0.0
+    for name, xf in (("range 2^+-40", base * scale), ("logit spread", spread), ("zeros", zeros)):
+        s_r, n_r, o_r, y_r = ref(xf)
+        e = {}
+        for eng in ("f32", "split"):
+            s, nrm = run(xf, eng)
+            y = run_y(xf, o_r, eng)
+            assert torch.isfinite(s).all() and torch.isfinite(nrm).all() and torch.isfinite(y).all(), (name, eng)
+            e[eng] = (err(s, s_r), err(nrm, n_r), err(y, y_r))
+        for q in range(3):
+            assert e["split"][q] <= 2 * e["f32"][q] + 2e-7, (name, q, e)
+            assert e["f32"][q] < 2e-5, (name, q, e)
+    # backward kernel on the same wide-range operands (dS / dn / O from the oracle so that errors do not compound)
+    xf = base * torch.from_numpy(np.exp2(rng.uniform(-12, 12, size=(B, N, 1))).astype(np.float32))
+    dy = _r(rng, B, N, C)
+    d = lambda t: t.double()
+    rb = orc.slice_core_backward(d(xf[..., :C]), d(xf[..., C:]), d(dy), d(ws), d(bs), d(temp), d(wq), d(wk), d(wv), heads)
+    o_ref = ref(xf)[2]
+    f32 = lambda t, *shape: g(t.float().reshape(*shape))
+    eb = {}
+    for eng in ("f32", "split"):
+        dxf, dws, dbs, dtemp = ops.slice_bwd_points(g(xf), g(dy), g(ws), g(bs), g(temp), f32(o_ref, B * heads, M, D),
+                                                    f32(rb["ds"], B * heads, M, D), f32(rb["dn"], B * heads, M),
+                                                    B, N, heads, D, M, engine=eng)
+        eb[eng] = (err(dxf[..., :C], rb["dxm"]), err(dxf[..., C:], rb["dfm"]), err(dws, rb["dws"]), err(dbs, rb["dbs"]))
+    for q in range(4):
+        assert eb["split"][q] <= 2 * eb["f32"][q] + 1e-6, (q, eb)
+    # +-inf / NaN: a poisoned x_mid row makes its point's weights NaN (all tokens of that (batch, head) and the point's own
+    # output row), a poisoned fx_mid value its channel of that (batch, head)'s tokens: the same entries on both engines
+    xp = base.clone()
+    xp[0, 17, 3] = float("inf")                  # x_mid, head 0
+    xp[1, 400, 2 * D + 1] = float("nan")         # x_mid, head 2
+    xp[0, 300, C + 5 * D + 7] = -float("inf")    # fx_mid, head 5, channel 7
+    o_fin = ref(base)[2]
+    m = {}
+    for eng in ("f32", "split"):
+        s, nrm = run(xp, eng)
+        y = run_y(xp, o_fin, eng)
+        m[eng] = (torch.isfinite(s).cpu(), torch.isfinite(nrm).cpu(), torch.isfinite(y).cpu())
+    for q in range(3):
+        assert torch.equal(m["f32"][q], m["split"][q]), q
+    bad_s, bad_y = ~m["split"][0], ~m["split"][2]
+    assert bad_s[0, 0].all() and bad_s[1, 2].all() and bad_s[0, 5, :, 7].all()
+    assert int(bad_s.sum()) == 2 * M * D + M                                # nothing else
+    assert bad_y[0, 17, :D].all() and bad_y[1, 400, 2 * D:3 * D].all() and int(bad_y.sum()) == 2 * D
 
 
 def _unplane(planes, rows, C, nt):

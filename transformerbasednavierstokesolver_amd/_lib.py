@@ -22,6 +22,7 @@ _st = C.c_void_p     # hipStream_t
 SIGNATURES = {
     "pa2d_version": (C.c_char_p, []),
     "pa2d_default_engine": (_i, []),
+    "pa2d_reload_env": (None, []),
     "pa2d_layernorm_fwd": (_i, [_f, _f, _f, _f, _f, _f, _i, _i, C.c_float, _st]),
     "pa2d_layernorm_bwd_workspace": (_sz, [_i, _i]),
     "pa2d_layernorm_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _st]),
@@ -37,15 +38,15 @@ SIGNATURES = {
     "pa2d_conv3x3x2_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _i, _i, _i, _st, _st,
                                 _st]),
     "pa2d_slice_nchunk": (_i, [_i, _i, _i]),
-    "pa2d_slice_scatter": (_i, [_f, _ll, _f, _ll, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _st, _st, _st]),
+    "pa2d_slice_scatter": (_i, [_f, _ll, _f, _ll, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _i, _st, _st, _st]),
     "pa2d_token_attn_lds_bytes": (_sz, [_i, _i, _i]),
     "pa2d_token_attn_fwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _i, _i, _i, _i, _st]),
     "pa2d_token_attn_bwd_workspace": (_sz, [_i, _i]),
     "pa2d_token_attn_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _i, _i, _st]),
-    "pa2d_deslice_fwd": (_i, [_f, _ll, _f, _f, _f, _f, _f, _ll, _i, _i, _i, _i, _i, _i, _st, _st, _st]),
+    "pa2d_deslice_fwd": (_i, [_f, _ll, _f, _f, _f, _f, _f, _ll, _i, _i, _i, _i, _i, _i, _i, _st, _st, _st]),
     "pa2d_slice_bwd_workspace": (_sz, [_i, _i, _i, _i, _i]),
     "pa2d_slice_bwd_points": (_i, [_f, _ll, _f, _ll, _f, _ll, _f, _f, _f, _f, _f, _f, _f, _ll, _f, _ll, _f, _f, _f,
-                                   _f, _sz, _i, _i, _i, _i, _i, _i, _i, _st, _st, _st]),
+                                   _f, _sz, _i, _i, _i, _i, _i, _i, _i, _i, _st, _st, _st]),
     "pa2d_head_fwd": (_i, [_f, _f, _f, _f, _i, _i, _i, _st]),
     "pa2d_head_bwd_workspace": (_sz, [_i, _i, _i]),
     "pa2d_head_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _i, _st]),
@@ -59,9 +60,13 @@ SIGNATURES = {
 }
 # bf16-storage variants: identical argument lists (activation pointers simply hold bf16); the GEMM / conv ones have no
 # `engine` argument (they ARE the bf16 engine)
-for _name in ("pa2d_layernorm_fwd", "pa2d_layernorm_bwd", "pa2d_slice_scatter", "pa2d_deslice_fwd", "pa2d_slice_bwd_points",
-              "pa2d_head_fwd", "pa2d_head_bwd"):
+for _name in ("pa2d_layernorm_fwd", "pa2d_layernorm_bwd", "pa2d_head_fwd", "pa2d_head_bwd"):
     SIGNATURES[_name + "_bf16"] = SIGNATURES[_name]
+# the slice stages: the fp32-storage entry points take `engine` (exact-fp32 MFMA or bf16 splits), the bf16-storage ones do not
+SIGNATURES["pa2d_slice_scatter_bf16"] = (_i, [_f, _ll, _f, _ll, _f, _f, _f, _f, _f, _i, _i, _i, _i, _i, _i, _st, _st, _st])
+SIGNATURES["pa2d_deslice_fwd_bf16"] = (_i, [_f, _ll, _f, _f, _f, _f, _f, _ll, _i, _i, _i, _i, _i, _i, _st, _st, _st])
+SIGNATURES["pa2d_slice_bwd_points_bf16"] = (_i, [_f, _ll, _f, _ll, _f, _ll, _f, _f, _f, _f, _f, _f, _f, _ll, _f, _ll, _f, _f,
+                                                 _f, _f, _sz, _i, _i, _i, _i, _i, _i, _i, _st, _st, _st])
 SIGNATURES.update({
     "pa2d_planes_bytes": (_sz, [_ll, _i, _i]),
     "pa2d_conv3x3x2_planes_mask": (_i, [_i, _i, _i, _i, _i]),

@@ -256,11 +256,7 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(const KCParams p, con
 }
 
 // 0 = never, 1 = when the launch fills the chip (default), 2 = always (tests): env PA2D_CONV_HALO=off|auto|force
-static int halo_policy() {
-    const char* e = getenv("PA2D_CONV_HALO");
-    if (!e || !e[0]) return 1;
-    return e[0] == 'o' ? 0 : (e[0] == 'f' ? 2 : 1);
-}
+static int halo_policy() { return pa2d_env().conv_halo; }
 
 bool conv_halo_applies(const KCParams& p) {
     const int pol = halo_policy();
@@ -277,30 +273,26 @@ int launch_conv_halo(const KCParams& p, hipStream_t st) {
     const dim3 grid(ceil_div(tiles_m, 8) * 8 * tiles_n);
     const int pitch = NT * 64 + 16;
     const int smem = HROWS * pitch + 2 * (NT == 1 ? 3 : 1) * BN * pitch;
-    static bool attr3 = false, attr1 = false;
+    // the LDS attribute is set on every launch: it is per device and the call is cheap
     if (NT == 3) {
-        if (!attr3) {
+        {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<3>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, smem);
             if (e != hipSuccess) return (int)e;
-            attr3 = true;
         }
         hipLaunchKernelGGL((conv_halo_kernel<3>), grid, dim3(512), smem, st, p, tiles_x, tiles_y, nimg);
     } else if (p.io_bf16) {
-        static bool attr1b = false;
-        if (!attr1b) {
+        {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<1, bf16_t>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, smem);
             if (e != hipSuccess) return (int)e;
-            attr1b = true;
         }
         hipLaunchKernelGGL((conv_halo_kernel<1, bf16_t>), grid, dim3(512), smem, st, p, tiles_x, tiles_y, nimg);
     } else {
-        if (!attr1) {
+        {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<1>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, smem);
             if (e != hipSuccess) return (int)e;
-            attr1 = true;
         }
         hipLaunchKernelGGL((conv_halo_kernel<1>), grid, dim3(512), smem, st, p, tiles_x, tiles_y, nimg);
     }

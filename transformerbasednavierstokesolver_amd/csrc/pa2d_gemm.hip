@@ -1,18 +1,39 @@
 // Engine selection, weight re-layouts and the C ABI of the dense (GEMM / conv) stages.  Kernels live in
 // pa2d_gemm_kc.hip (exact fp32), pa2d_gemm_split.hip (bf16 engines) and pa2d_gemm_mc.hip (weight gradients).
 #include "pa2d_gemm_common.h"
+#include <string.h>
 
 // Engines (explicit `engine` argument of every dense entry point; the library keeps NO engine state, so two
 // models in one process can use different engines): 0 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32), 1 = 6-term bf16
 // split at fp32 accuracy (conv GEMMs and large-M plain GEMMs; small GEMMs stay exact), 2 = bf16 compute for every GEMM (fp32 accumulate
 // and storage).  pa2d_default_engine() only reads the environment (PA2D_GEMM=f32|split|bf16), default = split.
 static bool engine_ok(int e) { return e >= 0 && e <= 2; }
+
+// ---- the one place the library reads the environment (pa2d_internal.h: Pa2dEnv)
+static Pa2dEnv read_env() {
+    auto is = [](const char* n, const char* pre) { const char* e = getenv(n); return e && strncmp(e, pre, strlen(pre)) == 0; };
+    auto num = [](const char* n, int dflt) { const char* e = getenv(n); return (e && e[0]) ? atoi(e) : dflt; };
+    Pa2dEnv v;
+    v.conv_halo = is("PA2D_CONV_HALO", "o") ? 0 : (is("PA2D_CONV_HALO", "f") ? 2 : 1);
+    v.mc_big_off = is("PA2D_MC_BIG", "o") ? 1 : 0;
+    v.kc_bk16 = num("PA2D_KC_BK", 0) == 16 ? 1 : 0;
+    v.mc_bk = num("PA2D_MC_BK", 16) == 32 ? 32 : 16;
+    v.mc_splits = num("PA2D_MC_SPLITS", 0);
+    v.mcb_splits = num("PA2D_MCB_SPLITS", 0);
+    v.lin_dw_split = is("PA2D_LIN_DW_SPLIT", "of") ? 0 : 1;
+    v.lin_panel = is("PA2D_LIN_PANEL", "of") ? 0 : 1;
+    v.split_big = num("PA2D_SPLIT_BIG", 1);
+    v.slice_map = is("PA2D_SLICE_MAP", "l") ? 0 : 1;
+    v.default_engine = is("PA2D_GEMM", "f") ? 0 : (is("PA2D_GEMM", "b") ? 2 : 1);
+    return v;
+}
+static Pa2dEnv g_env = read_env();
+const Pa2dEnv& pa2d_env() { return g_env; }
 // K-step: 32 (half the barriers of 16, full 128-byte row segments; 3-4 % faster on the conv, ~10 % on the small tiles)
 // whenever the layout allows it: plain GEMMs always, the conv when Cin % 32 == 0; otherwise 16.
 static int kc_bk(bool im2col, int Cin) {
-    static int force16 = -1;      // PA2D_KC_BK=16: 16-wide K-step for the conv (124 VGPRs, 40 KB LDS -> 4 workgroups per CU)
-    if (force16 < 0) { const char* e = getenv("PA2D_KC_BK"); force16 = (e && atoi(e) == 16) ? 1 : 0; }
-    if (im2col && force16) return 16;
+    // PA2D_KC_BK=16: 16-wide K-step for the conv (124 VGPRs, 40 KB LDS -> 4 workgroups per CU)
+    if (im2col && pa2d_env().kc_bk16) return 16;
     return (!im2col || (Cin % 32) == 0) ? 32 : 16;
 }
 // tile choice of the fp32 engine: 128x128 when that already gives >= 1.5 workgroups per CU, otherwise smaller
@@ -135,11 +156,9 @@ extern "C" {
 
 // The engine a caller should use when it has no preference: env PA2D_GEMM=f32|split|bf16, else the fp32-accurate
 // split engine.  A pure function of the environment — nothing in the library reads it implicitly.
-int pa2d_default_engine(void) {
-    const char* e = getenv("PA2D_GEMM");
-    if (!e || !e[0]) return 1;
-    return e[0] == 'f' ? 0 : (e[0] == 'b' ? 2 : 1);
-}
+int pa2d_default_engine(void) { return pa2d_env().default_engine; }
+
+void pa2d_reload_env(void) { g_env = read_env(); }
 
 int pa2d_gemm_bias_act_fwd(const float* x, long long ldx, const float* w, long long ldw, const float* bias,
                            const float* res, long long ldres, float* y, long long ldy, float* pre, long long ldpre,

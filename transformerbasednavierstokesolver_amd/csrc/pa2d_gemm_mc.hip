@@ -232,9 +232,8 @@ MCPlan plan_mc(int Mi, int Nj, int Mk) {
     // weight gradient: 8/16/24/32 splits -> 3.63/3.02/2.84/2.75 ms).
     const int max_splits = total_chunks / 8 > 0 ? total_chunks / 8 : 1;   // >= 8 chunks per split
     int best = max_splits < 8 ? max_splits : 8;
-    const char* env_s = getenv("PA2D_MC_SPLITS");                           // tuning knob
-    if (env_s) {
-        best = atoi(env_s);
+    if (pa2d_env().mc_splits > 0) {                                        // tuning knob PA2D_MC_SPLITS
+        best = pa2d_env().mc_splits;
     } else if (max_splits >= 8) {
         double best_eff = 0.0;
         for (int sp = 8; sp <= max_splits && sp <= 512; sp += 8) {
@@ -312,8 +311,7 @@ int launch_mc(const float* A, long long lda, int Mi, const float* B, long long l
     const int bm = pl.big ? 128 : 64;
     const dim3 grid(ceil_div(Mi, bm) * ceil_div(Nj, bm) * pl.splits);
     const bool bf = engine == 2;
-    static int mc_bk = -1;
-    if (mc_bk < 0) { const char* e = getenv("PA2D_MC_BK"); mc_bk = (e && atoi(e) == 32) ? 32 : 16; }
+    const int mc_bk = pa2d_env().mc_bk;
     if (pl.big && !bf && mc_bk == 32 && (pl.chunks_per_split % 2) == 0) {
         if (im2col) hipLaunchKernelGGL((gemm_mc_kernel<128, 128, true, 0, 32>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((gemm_mc_kernel<128, 128, false, 0, 32>), grid, dim3(256), 0, st, p);

@@ -446,8 +446,7 @@ MCPlan plan_mc_planes_big(int Mi, int Nj, int Mk) {
     const int tiles = ceil_div(Mi, 256) * ceil_div(Nj, 256);
     const int total_chunks = ceil_div(Mk, 16);
     int splits = 256 / tiles;
-    const char* env_s = getenv("PA2D_MCB_SPLITS");                          // tuning knob
-    if (env_s) splits = atoi(env_s);
+    if (pa2d_env().mcb_splits > 0) splits = pa2d_env().mcb_splits;         // tuning knob PA2D_MCB_SPLITS
     const int max_splits = total_chunks / 8 > 0 ? total_chunks / 8 : 1;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -459,8 +458,7 @@ MCPlan plan_mc_planes_big(int Mi, int Nj, int Mk) {
 
 // 0 = never, 1 = when the shape suits it (default), env PA2D_MC_BIG=off|auto
 bool mc_planes_big_applies(int C, int Cin, int Mk) {
-    const char* e = getenv("PA2D_MC_BIG");
-    if (e && e[0] == 'o') return false;
+    if (pa2d_env().mc_big_off) return false;
     return (C % 16) == 0 && (Cin % 32) == 0 && 2 * C >= 256 && 9 * Cin >= 256 && Mk >= 16 * 8 * 4;
 }
 
@@ -484,23 +482,21 @@ int launch_mc_planes_big_raw(const void* PA, int Mi, const void* PB, int Cin, in
     const int wgs = ceil_div(p.Mi, 256) * ceil_div(p.Nj, 256) * pl.splits;
     const int per_xcd = ceil_div(wgs, 8);
     const dim3 grid(per_xcd * 8);
-    static bool attr3 = false, attr1 = false;
+    // the LDS attribute is set on every launch: it is per device and the call is cheap
     if (NT == 3) {
         const int smem = 2 * 2 * 3 * 1 * 8192;
-        if (!attr3) {
+        {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mc_planes_big_kernel<3, 1>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, smem);
             if (e != hipSuccess) return (int)e;
-            attr3 = true;
         }
         hipLaunchKernelGGL((gemm_mc_planes_big_kernel<3, 1>), grid, dim3(512), smem, st, p, per_xcd);
     } else {
         const int smem = 2 * 2 * 1 * 4 * 8192;      // NT = 1: four 16-row K-steps per stage (64 MFMAs per wave and barrier)
-        if (!attr1) {
+        {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mc_planes_big_kernel<1, 4>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, smem);
             if (e != hipSuccess) return (int)e;
-            attr1 = true;
         }
         hipLaunchKernelGGL((gemm_mc_planes_big_kernel<1, 4>), grid, dim3(512), smem, st, p, per_xcd);
     }
@@ -511,9 +507,7 @@ int launch_mc_planes_big_raw(const void* PA, int Mi, const void* PB, int Cin, in
 // Plain dW = A^T . B of the bf16 engines straight from fp32 operands (A [Mk][lda] with Mi columns, B [Mk][ldb] with Nj
 // columns; Mi, Nj multiples of 8), 128 x 128 tiles on plan_mc's split plan; colsum (optional): [splits][Mi].
 bool mc_f32src_applies(int Mi, int Nj, int Mk, long long lda, long long ldb) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("PA2D_LIN_DW_SPLIT"); on = (e && e[0] == 'o' && e[1] == 'f') ? 0 : 1; }
-    return on && (Mi % 8) == 0 && (Nj % 8) == 0 && Mi > 64 && Nj > 64 && Mk >= 16 * 8 * 16 && (lda % 4) == 0 && (ldb % 4) == 0;
+    return pa2d_env().lin_dw_split && (Mi % 8) == 0 && (Nj % 8) == 0 && Mi > 64 && Nj > 64 && Mk >= 16 * 8 * 16 && (lda % 4) == 0 && (ldb % 4) == 0;
 }
 
 int launch_mc_f32src(const float* A, long long lda, int Mi, const float* B, long long ldb, int Nj, int Mk, float* slab,

@@ -275,12 +275,10 @@ int launch_panel_m(const KCParams& p, hipStream_t st) {
     constexpr int PITCHB = NT * 64 + 16;
     // >= 96 KB even when the stages are small, so that two workgroups never share a CU while another CU idles
     const int smem = 2 * 384 * PITCHB > 96 * 1024 ? 2 * 384 * PITCHB : 96 * 1024;
-    static bool attr_done = false;
-    if (!attr_done) {
+    {   // every launch: the attribute is per device, and the call is cheap
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_panel_kernel<NT, AF32, TO, MODE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         if (e != hipSuccess) return (int)e;
-        attr_done = true;
     }
     const int tiles_m = p.M / 256, tiles_n = ceil_div(p.N, 128);
     const int tmx = ceil_div(tiles_m, 8);
@@ -314,9 +312,7 @@ int launch_panel_t(const KCParams& p, hipStream_t st) {
 // Large-M plain GEMMs of the bf16 engines (fp32 storage: engines 1 / 2; bf16 storage: io_bf16).  PA2D_LIN_PANEL=off
 // sends them back to the per-tile kernels (A/B measurements).
 bool panel_applies(const KCParams& p, bool im2col) {
-    static int mode = -1;
-    if (mode < 0) { const char* e = getenv("PA2D_LIN_PANEL"); mode = (e && e[0] == 'o' && e[1] == 'f') ? 0 : 1; }
-    if (!mode || im2col) return false;
+    if (!pa2d_env().lin_panel || im2col) return false;
     // (bf16 storage stays on the per-tile kernels: with one MFMA term and 2-byte operands the layer is a pure streaming
     //  problem and two small workgroups per CU keep more bytes in flight than one persistent one: measured 131 vs 138
     //  samples/s on the bf16-storage bench)

@@ -282,24 +282,18 @@ int launch_kc_split(KCParams& p, bool im2col, hipStream_t st) {
     if (im2col && conv_halo_applies(p)) return launch_conv_halo(p, st);
     const dim3 grid(ceil_div(tiles_m, 8) * 8 * tiles_n);
     const int smem = 2 * (128 + 128) * (bf ? 80 : 208);
-    static bool attr_done = false;
-    if (!attr_done) {
+    {   // every launch: the attribute is per device, and the call is cheap
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kc_split_kernel<128, 128, true, 3, true>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (128 + 128) * 208);
         if (e != hipSuccess) return (int)e;
-        attr_done = true;
     }
-    static int big = -1;
-    if (big < 0) { const char* e = getenv("PA2D_SPLIT_BIG"); big = e ? atoi(e) : 1; }
-    if (big && im2col && !bf && (p.M % 256) == 0 && (long long)(p.M / 256) * tiles_n >= 512) {
+    if (pa2d_env().split_big && im2col && !bf && (p.M % 256) == 0 && (long long)(p.M / 256) * tiles_n >= 512) {
         // 256x128 workgroup tile (128x64 per consumer wave): 25 % less L2->LDS staging and LDS reads per MFMA
         const int smem_big = 2 * (256 + 128) * 208;
-        static bool attr_big = false;
-        if (!attr_big) {
+        {
             hipError_t eb = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kc_split_kernel<256, 128, true, 3, true>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, smem_big);
             if (eb != hipSuccess) return (int)eb;
-            attr_big = true;
         }
         const dim3 gbig(ceil_div(p.M / 256, 8) * 8 * tiles_n);
         hipLaunchKernelGGL((gemm_kc_split_kernel<256, 128, true, 3, true>), gbig, dim3(512), smem_big, st, p);

@@ -19,6 +19,7 @@
 #include <stdlib.h>
 
 #define NEG_BIG (-1e30f)
+#define PA2D_ENGINE_BF16_ID 2
 
 int pa2d_launch_reduce(const float* slab, int nslab, long long count, float* out, hipStream_t st);
 
@@ -780,8 +781,7 @@ int pa2d_slice_nchunk(int B, int N, int heads) {
     // at least 128 points (4 groups of 32) per unit; the token kernels sum any number of chunk records
     const int bh = B * heads > 0 ? B * heads : 1;
     if (N < 1) return 1;
-    static const int dbg_target = [] { const char* e = getenv("PA2D_DBG_NCHUNK_TARGET"); return e ? atoi(e) : 2048; }();   // DEV
-    int nchunk = ceil_div(dbg_target, bh);
+    int nchunk = ceil_div(2048, bh);
     const int maxc = ceil_div(N, 128);
     if (nchunk > maxc) nchunk = maxc;
     if (nchunk < 1) nchunk = 1;
@@ -789,15 +789,10 @@ int pa2d_slice_nchunk(int B, int N, int heads) {
     return ceil_div(N, ppc);
 }
 static int ppc_for(int N, int nchunk) { return ceil_div(ceil_div(N, nchunk), 32) * 32; }
-// bf16-MFMA forms of the forward kernels (pa2d_slice_bf.hip): the default; PA2D_SLICE_MFMA=f32 keeps the exact-fp32-MFMA
-// kernels of this file (A/B timing, and the reference the new ones are tested against)
-__attribute__((visibility("hidden"))) int pa2d_launch_scatter_bf(const void* xm, long long ldx, const void* v, long long ldv, const float* ws, const float* bs,
-                           const float* temperature, float* spart, float* npart, int B, int N, int heads, int D, int M,
-                           int mt, int nchunk, int ppc, unsigned x_bytes, unsigned v_bytes, int clamp, int xcd_map, bool bf,
-                           hipStream_t st);
-__attribute__((visibility("hidden"))) int pa2d_launch_deslice_bf(const void* xm, long long ldx, const float* o, const float* ws, const float* bs,
-                           const float* temperature, void* y, long long ldy, int B, int N, int heads, int D, int M, int mt,
-                           int nchunk, int ppc, unsigned x_bytes, unsigned y_bytes, int clamp, int xcd_map, bool bf, hipStream_t st);
+// The slice stages exist twice.  PA2D_ENGINE_F32: the kernels of this file, every contraction on the exact-fp32 matrix
+// instruction (v_mfma_f32_16x16x4_f32).  PA2D_ENGINE_SPLIT / _BF16 and the bf16-storage entry points: the v3 kernels
+// (pa2d_slice3.hip, pa2d_slice3_bwd.hip), bf16 MFMA on exact 3-plane operand splits with fp32 accumulation.  The choice
+// is the caller's `engine` argument — nothing here reads the environment for it.
 __attribute__((visibility("hidden"))) int pa2d_launch_scatter3(const void* xm, long long ldx, const void* v, long long ldv, const float* ws, const float* bs,
                            const float* temperature, float* spart, float* npart, int B, int N, int heads, int D, int M,
                            int mt, int nchunk, int ppc, unsigned x_bytes, unsigned v_bytes, int clamp, int xcd_map, bool bf,
@@ -823,30 +818,17 @@ static int bwd_nchunk(int B, int N, int heads) {
     const int ppc = ceil_div(ceil_div(N, nchunk), 32) * 32;
     return ceil_div(N, ppc);
 }
-static int slice_version() {          // development switch: PA2D_SLICE_V=2 keeps the round-2 bf16-MFMA kernels
-    static const int v = [] { const char* e = getenv("PA2D_SLICE_V"); return (e && e[0] == '2') ? 2 : 3; }();
-    return v;
-}
-static int slice_xcd_map() {          // PA2D_SLICE_MAP=legacy keeps the chunk-fastest numbering (A/B timing)
-    const char* e = getenv("PA2D_SLICE_MAP");
-    return (e && e[0] == 'l') ? 0 : 1;
-}
-// PA2D_SLICE_MFMA=f32 forces the exact-fp32-MFMA kernels of this file; default: bf16 MFMA (measured at the bench shape,
-// fp32 storage: scatter 0.120 vs 0.131 ms, de-slice 0.098 vs 0.108 ms; bf16 storage: scatter 0.077 vs 0.120 ms)
-static bool slice_on_bf16_mfma(bool scatter, bool bf) {
-    (void)scatter; (void)bf;
-    const char* e = getenv("PA2D_SLICE_MFMA");
-    return !(e && e[0] == 'f');
-}
+static int slice_xcd_map() { return pa2d_env().slice_map; }      // PA2D_SLICE_MAP=legacy: chunk-fastest numbering (A/B timing)
+static bool slice_v3(int engine, bool bf) { return bf || engine != 0; }
 size_t pa2d_slice_bwd_workspace(int B, int N, int heads, int D, int M);
 
 // spart [B,heads,nchunk,M,D], npart [B,heads,nchunk,M] (NULL to skip the norm); bf: activations stored as bf16
 static int slice_scatter_impl(const void* xm, long long ldx, const void* v, long long ldv, const float* ws,
                               const float* bs, const float* temperature, float* spart, float* npart, int B, int N,
-                              int heads, int D, int M, int clamp_temperature, hipStream_t st, hipEvent_t ev_start,
+                              int heads, int D, int M, int clamp_temperature, int engine, hipStream_t st, hipEvent_t ev_start,
                               hipEvent_t ev_stop, bool bf) {
     const int mt = mt_for(M);
-    if ((ldx & 3) || (D & 7)) return PA2D_ERR_ARG;
+    if ((ldx & 3) || (D & 7) || engine < 0 || engine > 2) return PA2D_ERR_ARG;
     if (B <= 0 || N <= 0) return PA2D_OK;
     const unsigned long long es = bf ? 2ull : 4ull;
     SliceParams p;
@@ -863,13 +845,9 @@ static int slice_scatter_impl(const void* xm, long long ldx, const void* v, long
     }
     const int grid = B * heads * p.nchunk;
     if (ev_start && hipEventRecord(ev_start, st) != hipSuccess) return PA2D_ERR_ARG;
-    if (slice_on_bf16_mfma(true, bf) && slice_version() == 3) {
+    if (slice_v3(engine, bf)) {
         const int rc = pa2d_launch_scatter3(xm, ldx, v, ldv, ws, bs, temperature, spart, npart, B, N, heads, D, M, mt,
                                             p.nchunk, p.ppc, p.x_bytes, p.v_bytes, clamp_temperature, p.xcd_map, bf, st);
-        if (rc) return rc;
-    } else if (slice_on_bf16_mfma(true, bf)) {
-        const int rc = pa2d_launch_scatter_bf(xm, ldx, v, ldv, ws, bs, temperature, spart, npart, B, N, heads, D, M, mt,
-                                              p.nchunk, p.ppc, p.x_bytes, p.v_bytes, clamp_temperature, p.xcd_map, bf, st);
         if (rc) return rc;
     } else {
 #define CALL_SC(D_, MT_) launch_scatter_t<D_, MT_>(p, grid, st, bf)
@@ -882,9 +860,9 @@ static int slice_scatter_impl(const void* xm, long long ldx, const void* v, long
 
 static int deslice_impl(const void* xm, long long ldx, const float* o, const float* ws, const float* bs,
                         const float* temperature, void* y, long long ldy, int B, int N, int heads, int D, int M,
-                        int clamp_temperature, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop, bool bf) {
+                        int clamp_temperature, int engine, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop, bool bf) {
     const int mt = mt_for(M);
-    if ((ldx & 3) || (ldy & 3) || (D & 7)) return PA2D_ERR_ARG;
+    if ((ldx & 3) || (ldy & 3) || (D & 7) || engine < 0 || engine > 2) return PA2D_ERR_ARG;
     if (B <= 0 || N <= 0) return PA2D_OK;
     const unsigned long long es = bf ? 2ull : 4ull;
     DesliceParams p;
@@ -901,13 +879,9 @@ static int deslice_impl(const void* xm, long long ldx, const float* o, const flo
     }
     const int grid = B * heads * p.nchunk;
     if (ev_start && hipEventRecord(ev_start, st) != hipSuccess) return PA2D_ERR_ARG;
-    if (slice_on_bf16_mfma(false, bf) && slice_version() == 3) {
+    if (slice_v3(engine, bf)) {
         const int rc = pa2d_launch_deslice3(xm, ldx, o, ws, bs, temperature, y, ldy, B, N, heads, D, M, mt, p.nchunk, p.ppc,
                                             p.x_bytes, p.y_bytes, clamp_temperature, bf, st);
-        if (rc) return rc;
-    } else if (slice_on_bf16_mfma(false, bf)) {
-        const int rc = pa2d_launch_deslice_bf(xm, ldx, o, ws, bs, temperature, y, ldy, B, N, heads, D, M, mt, p.nchunk, p.ppc,
-                                              p.x_bytes, p.y_bytes, clamp_temperature, p.xcd_map, bf, st);
         if (rc) return rc;
     } else {
 #define CALL_DS(D_, MT_) launch_deslice_t<D_, MT_>(p, grid, st, bf)
@@ -923,10 +897,11 @@ static int slice_bwd_impl(const void* xm, long long ldx, const void* fm, long lo
                           const float* ws, const float* bs, const float* temperature, const float* o, const float* ds,
                           const float* dn, void* dxm, long long lddx, void* dfm, long long lddf, float* dws, float* dbs,
                           float* dtemperature, void* ws_buf, size_t ws_bytes, int B, int N, int heads, int D, int M,
-                          int clamp_temperature, int accumulate, hipStream_t st, hipEvent_t ev_start,
+                          int clamp_temperature, int accumulate, int engine, hipStream_t st, hipEvent_t ev_start,
                           hipEvent_t ev_stop, bool bf, void* planes = nullptr, int planes_nt = 0, float* dbx = nullptr,
                           float* dbf = nullptr, const float* nrm = nullptr) {
     const int mt = mt_for(M);
+    if (engine < 0 || engine > 2) return PA2D_ERR_ARG;
     if ((ldx & 3) || (ldf & 3) || (lddy & 3) || (lddx & 3) || (lddf & 3) || (D & 7)) return PA2D_ERR_ARG;
     if (B <= 0 || N <= 0) {
         if (accumulate) return PA2D_OK;
@@ -966,7 +941,7 @@ static int slice_bwd_impl(const void* xm, long long ldx, const void* fm, long lo
     const int grid = B * heads * p.nchunk;
     int rc = PA2D_OK;
     if (ev_start && hipEventRecord(ev_start, st) != hipSuccess) return PA2D_ERR_ARG;
-    if (slice_on_bf16_mfma(false, bf) && slice_version() == 3) {
+    if (slice_v3(engine, bf)) {
         if (planes && !nrm) return PA2D_ERR_ARG;
         rc = pa2d_launch_slice_bwd3(p.xm, p.ldx, p.fm, p.ldf, p.dy, p.lddy, ws, bs, temperature, o, ds, dn, nrm, p.dxm, p.lddx, p.dfm,
                                     p.lddf, p.planes, p.planes_bytes, p.planes_nt, p.stride, p.part, B, N, heads, D, M, mt,
@@ -1004,30 +979,30 @@ static int slice_bwd_impl(const void* xm, long long ldx, const void* fm, long lo
 
 int pa2d_slice_scatter(const float* xm, long long ldx, const float* v, long long ldv, const float* ws,
                        const float* bs, const float* temperature, float* spart, float* npart, int B, int N,
-                       int heads, int D, int M, int clamp_temperature, hipStream_t st, hipEvent_t ev_start,
+                       int heads, int D, int M, int clamp_temperature, int engine, hipStream_t st, hipEvent_t ev_start,
                        hipEvent_t ev_stop) {
-    return slice_scatter_impl(xm, ldx, v, ldv, ws, bs, temperature, spart, npart, B, N, heads, D, M, clamp_temperature, st,
-                              ev_start, ev_stop, false);
+    return slice_scatter_impl(xm, ldx, v, ldv, ws, bs, temperature, spart, npart, B, N, heads, D, M, clamp_temperature,
+                              engine, st, ev_start, ev_stop, false);
 }
 int pa2d_slice_scatter_bf16(const void* xm, long long ldx, const void* v, long long ldv, const float* ws,
                             const float* bs, const float* temperature, float* spart, float* npart, int B, int N,
                             int heads, int D, int M, int clamp_temperature, hipStream_t st, hipEvent_t ev_start,
                             hipEvent_t ev_stop) {
-    return slice_scatter_impl(xm, ldx, v, ldv, ws, bs, temperature, spart, npart, B, N, heads, D, M, clamp_temperature, st,
-                              ev_start, ev_stop, true);
+    return slice_scatter_impl(xm, ldx, v, ldv, ws, bs, temperature, spart, npart, B, N, heads, D, M, clamp_temperature,
+                              PA2D_ENGINE_BF16_ID, st, ev_start, ev_stop, true);
 }
 
 int pa2d_deslice_fwd(const float* xm, long long ldx, const float* o, const float* ws, const float* bs,
                      const float* temperature, float* y, long long ldy, int B, int N, int heads, int D, int M,
-                     int clamp_temperature, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
-    return deslice_impl(xm, ldx, o, ws, bs, temperature, y, ldy, B, N, heads, D, M, clamp_temperature, st, ev_start, ev_stop,
-                        false);
+                     int clamp_temperature, int engine, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    return deslice_impl(xm, ldx, o, ws, bs, temperature, y, ldy, B, N, heads, D, M, clamp_temperature, engine, st, ev_start,
+                        ev_stop, false);
 }
 int pa2d_deslice_fwd_bf16(const void* xm, long long ldx, const float* o, const float* ws, const float* bs,
                           const float* temperature, void* y, long long ldy, int B, int N, int heads, int D, int M,
                           int clamp_temperature, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
-    return deslice_impl(xm, ldx, o, ws, bs, temperature, y, ldy, B, N, heads, D, M, clamp_temperature, st, ev_start, ev_stop,
-                        true);
+    return deslice_impl(xm, ldx, o, ws, bs, temperature, y, ldy, B, N, heads, D, M, clamp_temperature, PA2D_ENGINE_BF16_ID, st,
+                        ev_start, ev_stop, true);
 }
 
 size_t pa2d_slice_bwd_workspace(int B, int N, int heads, int D, int M) {
@@ -1039,11 +1014,11 @@ int pa2d_slice_bwd_points(const float* xm, long long ldx, const float* fm, long 
                           long long lddy, const float* ws, const float* bs, const float* temperature,
                           const float* o, const float* ds, const float* dn, float* dxm, long long lddx, float* dfm,
                           long long lddf, float* dws, float* dbs, float* dtemperature, void* ws_buf, size_t ws_bytes,
-                          int B, int N, int heads, int D, int M, int clamp_temperature, int accumulate, hipStream_t st,
-                          hipEvent_t ev_start, hipEvent_t ev_stop) {
+                          int B, int N, int heads, int D, int M, int clamp_temperature, int accumulate, int engine,
+                          hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
     return slice_bwd_impl(xm, ldx, fm, ldf, dy, lddy, ws, bs, temperature, o, ds, dn, dxm, lddx, dfm, lddf, dws, dbs,
-                          dtemperature, ws_buf, ws_bytes, B, N, heads, D, M, clamp_temperature, accumulate, st, ev_start,
-                          ev_stop, false);
+                          dtemperature, ws_buf, ws_bytes, B, N, heads, D, M, clamp_temperature, accumulate, engine, st,
+                          ev_start, ev_stop, false);
 }
 int pa2d_slice_bwd_points_bf16(const void* xm, long long ldx, const void* fm, long long ldf, const void* dy,
                                long long lddy, const float* ws, const float* bs, const float* temperature,
@@ -1052,8 +1027,8 @@ int pa2d_slice_bwd_points_bf16(const void* xm, long long ldx, const void* fm, lo
                                size_t ws_bytes, int B, int N, int heads, int D, int M, int clamp_temperature,
                                int accumulate, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
     return slice_bwd_impl(xm, ldx, fm, ldf, dy, lddy, ws, bs, temperature, o, ds, dn, dxm, lddx, dfm, lddf, dws, dbs,
-                          dtemperature, ws_buf, ws_bytes, B, N, heads, D, M, clamp_temperature, accumulate, st, ev_start,
-                          ev_stop, true);
+                          dtemperature, ws_buf, ws_bytes, B, N, heads, D, M, clamp_temperature, accumulate,
+                          PA2D_ENGINE_BF16_ID, st, ev_start, ev_stop, true);
 }
 
 // Same, but [dX | dF] leaves ONLY as the bf16 plane image the conv GEMMs of `engine` stage (NT = 3 planes for
@@ -1069,8 +1044,8 @@ int pa2d_slice_bwd_points_planes(const float* xm, long long ldx, const float* fm
     if (engine != 1 && engine != 2) return PA2D_ERR_ARG;
     if (!dxf_planes || !dbx || !dbf || !nrm) return PA2D_ERR_ARG;
     return slice_bwd_impl(xm, ldx, fm, ldf, dy, lddy, ws, bs, temperature, o, ds, dn, nullptr, 0, nullptr, 0, dws, dbs,
-                          dtemperature, ws_buf, ws_bytes, B, N, heads, D, M, clamp_temperature, accumulate, st, ev_start,
-                          ev_stop, false, dxf_planes, engine == 2 ? 1 : 3, dbx, dbf, nrm);
+                          dtemperature, ws_buf, ws_bytes, B, N, heads, D, M, clamp_temperature, accumulate, engine, st,
+                          ev_start, ev_stop, false, dxf_planes, engine == 2 ? 1 : 3, dbx, dbf, nrm);
 }
 
 }  // extern "C"

@@ -49,9 +49,9 @@ def attn_forward(xn, P, res, H, W, heads, engine=None, xn_planes=None, shape=Non
         wcat, bcat = torch.cat((P["wx"], P["wf"]), 0), torch.cat((P["bx"], P["bf"]), 0)
         xf = ops.linear_fwd(xn.view(B * N, C), wcat, bcat, engine=engine)[0].view(B, N, 2 * C)
     spart, npart = ops.slice_scatter(xf, 2 * C, 0, xf, 2 * C, C, P["ws"], P["bs"], temp, B, N, heads, D, M,
-                                     clamp=structured)
+                                     clamp=structured, engine=engine)
     s, nrm, o = ops.token_attn_fwd(spart, npart, P["wq"], P["wk"], P["wv"])
-    y = ops.deslice_fwd(xf, 2 * C, 0, o, P["ws"], P["bs"], temp, B, N, heads, D, M, clamp=structured)  # [B,N,C]
+    y = ops.deslice_fwd(xf, 2 * C, 0, o, P["ws"], P["bs"], temp, B, N, heads, D, M, clamp=structured, engine=engine)  # [B,N,C]
     out, _ = ops.linear_fwd(y.view(B * N, C), P["wo"], P["bo"],
                             res=None if res is None else res.reshape(B * N, C), engine=engine)
     return out.view(B, N, C), (xn if xn_planes is None else xn_planes, xf, s, nrm, o, y, temp)
@@ -73,7 +73,7 @@ def attn_backward(saved, P, dout, H, W, heads, need_dx=True, engine=None, target
     dy = ops.linear_bwd_data(d2, P["wo"], engine=engine)                                      # [B*N,C]
     dwo, dbo = ops.linear_bwd_weight(d2, y.view(B * N, C), engine=engine, into=t("wo", "bo"))
     dopart, _ = ops.slice_scatter(xf, 2 * C, 0, dy, C, 0, P["ws"], P["bs"], temp, B, N, heads, D, M,
-                                  want_norm=False, clamp=structured)
+                                  want_norm=False, clamp=structured, engine=engine)
     ds, dn, dwq, dwk, dwv = ops.token_attn_bwd(s, nrm, P["wq"], P["wk"], P["wv"], dopart, into=t("wq", "wk", "wv"))
     if planes:
         dxfp, dbx, dbf, dws, dbs, dtemp = ops.slice_bwd_points_planes(xf, dy, P["ws"], P["bs"], temp, o, ds, dn, nrm, B, N, heads,
@@ -86,7 +86,7 @@ def attn_backward(saved, P, dout, H, W, heads, need_dx=True, engine=None, target
         return dxn, dict(temperature=dtemp.view(1, heads, 1, 1), wx=dwx, bx=dbx, wf=dwf, bf=dbf, ws=dws, bs=dbs,
                          wq=dwq, wk=dwk, wv=dwv, wo=dwo, bo=dbo)
     dxf, dws, dbs, dtemp = ops.slice_bwd_points(xf, dy, P["ws"], P["bs"], temp, o, ds, dn, B, N, heads, D, M,
-                                                clamp=structured, into=t("ws", "bs", "temperature"))
+                                                clamp=structured, into=t("ws", "bs", "temperature"), engine=engine)
     if structured:
         dxn, dwx, dbx, dwf, dbf = ops.conv3x3x2_bwd(dxf, xn, P["wx"], P["wf"], H, W, need_dx=need_dx, engine=engine,
                                                     into=t("wx", "bx", "wf", "bf"))

@@ -405,8 +405,13 @@ def slice_nchunk(B, N, heads):
     return _L().pa2d_slice_nchunk(B, N, heads)
 
 
+def _slice_engine_args(engine, bf):
+    """The slice entry points of fp32 storage take the engine (exact-fp32 MFMA kernels vs bf16 splits); bf16 storage has none."""
+    return () if bf else (_abi_engine(engine),)
+
+
 def slice_scatter(xm, ldx, xm_off, v, ldv, v_off, ws_w, bs, temperature, B, N, heads, D, M, want_norm=True,
-                  clamp=True):
+                  clamp=True, engine=None):
     """Partial sums of W^T V per point chunk.  xm / v are base tensors; *_off are float offsets."""
     _chk(ws_w, bs, temperature)
     bf = _chk_act(xm, v)
@@ -415,7 +420,8 @@ def slice_scatter(xm, ldx, xm_off, v, ldv, v_off, ws_w, bs, temperature, B, N, h
     npart = torch.empty(B * heads, nchunk, M, dtype=torch.float32, device=xm.device) if want_norm else None
     e0, e1 = _events("slice_scatter")
     _lib.check(_fn("pa2d_slice_scatter", bf)(_p(xm, xm_off), ldx, _p(v, v_off), ldv, _p(ws_w), _p(bs), _p(temperature),
-                                       _p(spart), _p(npart), B, N, heads, D, M, int(clamp), _stream(), e0, e1),
+                                       _p(spart), _p(npart), B, N, heads, D, M, int(clamp), *_slice_engine_args(engine, bf),
+                                       _stream(), e0, e1),
                "slice_scatter")
     return spart, npart
 
@@ -445,17 +451,18 @@ def token_attn_bwd(s, nrm, wq, wk, wv, dopart, into=None):
     return ds, dn, dwq, dwk, dwv
 
 
-def deslice_fwd(xm, ldx, xm_off, o, ws_w, bs, temperature, B, N, heads, D, M, clamp=True):
+def deslice_fwd(xm, ldx, xm_off, o, ws_w, bs, temperature, B, N, heads, D, M, clamp=True, engine=None):
     _chk(o, ws_w, bs, temperature)
     bf = _chk_act(xm)
     y = torch.empty(B, N, heads * D, dtype=xm.dtype, device=xm.device)
     e0, e1 = _events("deslice")
     _lib.check(_fn("pa2d_deslice_fwd", bf)(_p(xm, xm_off), ldx, _p(o), _p(ws_w), _p(bs), _p(temperature), _p(y), heads * D,
-                                     B, N, heads, D, M, int(clamp), _stream(), e0, e1), "deslice_fwd")
+                                     B, N, heads, D, M, int(clamp), *_slice_engine_args(engine, bf), _stream(), e0, e1),
+               "deslice_fwd")
     return y
 
 
-def slice_bwd_points(xf, dy, ws_w, bs, temperature, o, ds, dn, B, N, heads, D, M, clamp=True, into=None):
+def slice_bwd_points(xf, dy, ws_w, bs, temperature, o, ds, dn, B, N, heads, D, M, clamp=True, into=None, engine=None):
     """xf = [B,N,2C] ([x_mid | fx_mid]); returns dxf [B,N,2C], dws, dbs, dtemperature [heads]."""
     _chk(ws_w, bs, temperature, o, ds, dn)
     bf = _chk_act(xf, dy)
@@ -468,7 +475,8 @@ def slice_bwd_points(xf, dy, ws_w, bs, temperature, o, ds, dn, B, N, heads, D, M
     _lib.check(_fn("pa2d_slice_bwd_points", bf)(_p(xf), 2 * Cc, _p(xf, Cc), 2 * Cc, _p(dy), Cc, _p(ws_w), _p(bs),
                                           _p(temperature), _p(o), _p(ds), _p(dn), _p(dxf), 2 * Cc, _p(dxf, Cc),
                                           2 * Cc, _p(dws), _p(dbs), _p(dtemp), ws.data_ptr(), nb, B, N, heads, D, M,
-                                          int(clamp), acc, _stream(), e0, e1), "slice_bwd_points")
+                                          int(clamp), acc, *_slice_engine_args(engine, bf), _stream(), e0, e1),
+               "slice_bwd_points")
     return dxf, dws, dbs, dtemp
 
 
