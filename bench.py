@@ -63,8 +63,20 @@ ENGINE_LABEL = {ops.ENGINE_F32: "exact fp32 MFMA (all GEMMs)",
 # fx_mid, dY and writes dX, dF — as e-byte tensors (5 units), or, when the engine takes the conv operands as bf16 plane
 # images (ops.conv_planes_mask == 7), as the NT-plane image the conv multiplies: 3 + 2 * NT * 2 / 4 units (split: 6,
 # bf16 compute: 4), which replaces the separate split pass and its traffic
-HBM_KERNELS = {"slice_scatter": ("slice_scatter_kernel", 2.0), "deslice": ("deslice_kernel", 2.0),
-               "slice_bwd": ("slice_bwd_kernel", 5.0)}
+HBM_KERNELS = {"slice_scatter": 2.0, "deslice": 2.0, "slice_bwd": 5.0}
+
+
+def slice_kernel_names(engine, D, M, planes):
+    """The names rocprofv3 prints for the three slice-path kernels of a (engine, head dim, slices) workload."""
+    mt = 1 if M <= 16 else 2 if M <= 32 else 4 if M <= 64 else 8
+    if engine == ops.ENGINE_F32:
+        return {"slice_scatter": f"slice_scatter_kernel<{D}, {mt}, float>", "deslice": f"deslice_kernel<{D}, {mt}, float>",
+                "slice_bwd": f"slice_bwd_kernel<{D}, {mt}, float, 0>"}
+    t = "__bf16" if engine == ops.ENGINE_BF16S else "float"
+    pl = (3 if engine == ops.ENGINE_SPLIT else 1) if planes and engine != ops.ENGINE_BF16S else 0
+    # fp32 storage with M = 128: the backward stays on the fp32-MFMA kernel (pa2d_slice3_bwd.hip)
+    bwd = f"slice_bwd_kernel<{D}, {mt}, float, {pl}>" if (mt == 8 and t == "float") else f"slice_bwd3_kernel<{D}, {mt}, {t}, {pl}>"
+    return {"slice_scatter": f"scatter3_kernel<{D}, {mt}, {t}>", "deslice": f"deslice3_kernel<{D}, {mt}, {t}>", "slice_bwd": bwd}
 
 
 class HipEventPool:
@@ -268,12 +280,18 @@ class Ranks:
             if before_step is not None:
                 before_step(i)
             out = fn()
+        torch.cuda.synchronize()
+        own = time.perf_counter() - t0                      # this rank's time before the closing barrier
         self.barrier()
         dt = time.perf_counter() - t0
+        self.last_rank_ms = None
         if self.world > 1:
             tt = torch.tensor([dt], device=self.dev, dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
+            allr = [torch.zeros(1, device=self.dev, dtype=torch.float64) for _ in range(self.world)]
+            dist.all_gather(allr, torch.tensor([own], device=self.dev, dtype=torch.float64))
+            self.last_rank_ms = [round(1e3 * float(t.item()) / steps, 2) for t in allr]
         return dt, out
 
     def close(self):
@@ -282,7 +300,7 @@ class Ranks:
             dist.destroy_process_group()
 
 
-def rooflines(ms_by_kind, engine, rows, C, traffic=None, planes=False):
+def rooflines(ms_by_kind, engine, rows, C, traffic=None, planes=False, heads=8, M=64):
     """(roofline, roofline_hbm) dicts from the live HIP-event durations of one workload (rows = B*N).  planes: the slice
     backward of this workload emits the conv's plane image (see HBM_KERNELS)."""
     roof = hbm = None
@@ -300,28 +318,31 @@ def rooflines(ms_by_kind, engine, rows, C, traffic=None, planes=False):
                 "peak_note": ("fp32-equivalent: dense bf16 MFMA peak / 6 terms" if engine == ops.ENGINE_SPLIT else
                               ("dense bf16 MFMA" if engine in (ops.ENGINE_BF16, ops.ENGINE_BF16S) else "fp32 MFMA"))}
     planes = planes and engine in (ops.ENGINE_SPLIT, ops.ENGINE_BF16)       # bf16 STORAGE writes plain bf16 tensors
-    bwd_units = 3.0 + 2.0 * (3 if engine == ops.ENGINE_SPLIT else 1) * 2.0 / 4.0 if planes else HBM_KERNELS["slice_bwd"][1]
-    kernels, tot_b, tot_ms = [], 0.0, 0.0
-    for kind, (kname, units) in HBM_KERNELS.items():
+    bwd_units = 3.0 + 2.0 * (3 if engine == ops.ENGINE_SPLIT else 1) * 2.0 / 4.0 if planes else HBM_KERNELS["slice_bwd"]
+    names = slice_kernel_names(engine, C // heads, M, planes)
+    kernels, tot_b, tot_bs, tot_ms = [], 0.0, 0.0, 0.0
+    for kind, units in HBM_KERNELS.items():
         ms = ms_by_kind.get(kind) or []
         if not ms:
             continue
-        if kind == "slice_bwd":
-            units = bwd_units
-        nbytes = units * rows * C * esize
+        survey_bytes = units * rows * C * esize                 # 2 / 2 / 5 x R*C*e
+        nbytes = (bwd_units if kind == "slice_bwd" else units) * rows * C * esize       # what this engine's kernel moves
         avg = float(np.mean(ms))
-        gbs = nbytes / (avg * 1e-3) / 1e9
-        kernels.append({"kernel": kname, "bytes_per_launch": nbytes, "avg_launch_ms": round(avg, 4),
-                        "launches_timed": len(ms), "achieved": round(gbs, 1), "frac": round(gbs / PEAK_HBM_GBS, 4)})
+        gbs, gbs_s = nbytes / (avg * 1e-3) / 1e9, survey_bytes / (avg * 1e-3) / 1e9
+        kernels.append({"kernel": names[kind], "bytes_per_launch": nbytes, "avg_launch_ms": round(avg, 4),
+                        "launches_timed": len(ms), "achieved": round(gbs, 1), "frac": round(gbs / PEAK_HBM_GBS, 4),
+                        "survey_bytes_per_launch": survey_bytes, "frac_survey_bytes": round(gbs_s / PEAK_HBM_GBS, 4)})
         tot_b += nbytes * len(ms)
+        tot_bs += survey_bytes * len(ms)
         tot_ms += float(np.sum(ms))
     if kernels:
-        ach = tot_b / (tot_ms * 1e-3) / 1e9
+        ach, ach_s = tot_b / (tot_ms * 1e-3) / 1e9, tot_bs / (tot_ms * 1e-3) / 1e9
         hbm = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-               "frac": round(ach / PEAK_HBM_GBS, 4), "traffic": None,
-               "note": "launch-weighted over the three slice-path kernels; algorithmic bytes per launch = "
-                       f"2 / 2 / {bwd_units:g} x R*C*{int(esize)} B (DESIGN.md §4)"
-                       + ("; the slice backward writes dX | dF as the conv's bf16 plane image" if planes else ""),
+               "frac": round(ach / PEAK_HBM_GBS, 4), "frac_survey_bytes": round(ach_s / PEAK_HBM_GBS, 4), "traffic": None,
+               "note": "launch-weighted over the three slice-path kernels (names as rocprofv3 prints them); `frac`: bytes "
+                       f"this engine's kernels move = 2 / 2 / {bwd_units:g} x R*C*{int(esize)} B"
+                       + (" (the slice backward writes dX | dF as the conv's bf16 plane image)" if planes else "")
+                       + "; `frac_survey_bytes`: SURVEY §8(d) bytes 2 / 2 / 5 x R*C*e",
                "kernels": kernels}
     return roof, hbm
 
@@ -350,7 +371,8 @@ def darcy_leg(rk, pool, engine, batch, steps):
     dt, (loss, l2, _) = rk.timed(step, steps)
     pool.enabled = False
     roof, hbm = rooflines(pool.drain_ms(), engine, batch * s * s, cfg["n_hidden"],
-                          planes=ops.conv_planes_mask(batch, s, s, cfg["n_hidden"], engine) == 7)
+                          planes=ops.conv_planes_mask(batch, s, s, cfg["n_hidden"], engine) == 7,
+                          heads=cfg["n_head"], M=cfg["slice_num"])
     fwd_gflop = 1143.0          # forward GFLOP per sample per call at this geometry
     out = {"workload": f"exp_darcy.py iteration, Darcy 421x421 (N=177241), Transolver_Structured_Mesh_2D 8 layers, "
                        f"C=128, 8 heads, M=128 slices, batch {batch}/GPU (BASELINE configs[4] geometry), "
@@ -376,6 +398,9 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=3)
     ap.add_argument("--cpu-budget-s", type=float, default=330.0, help="wall-clock budget of the CPU training iterations")
     ap.add_argument("--no-rollout", action="store_true")
+    ap.add_argument("--rollout-repeats", type=int, default=7, help="timed 20-step rollouts per batch size (median reported)")
+    ap.add_argument("--no-bf16-leg", action="store_true",
+                    help="skip the secondary bf16-storage measurement (BASELINE configs[2] / [4] as stated)")
     ap.add_argument("--graph", action="store_true",
                     help="replay forward+backward from one hipGraph (launch-bound small batches); disables the per-kernel HIP events")
     ap.add_argument("--fold-time", action="store_true",
@@ -447,8 +472,12 @@ def main():
 
     def gate(i):
         pool.enabled = i < args.roofline_steps
+    sync.timing = world > 1
     dt, (loss, full) = rk.timed(step, args.steps, before_step=gate)
     pool.enabled = False
+    rank_ms = rk.last_rank_ms
+    ar_ms = sync.drain_allreduce_ms() if world > 1 else []
+    sync.timing = False
     log(f"{args.steps} timed steps in {dt:.2f} s")
 
     traffic = None
@@ -463,7 +492,8 @@ def main():
         except Exception:
             traffic = None
     roof, roof_hbm = rooflines(pool.drain_ms(), engine, B * (calls if args.fold_time else 1) * N, C, traffic,
-                               planes=ops.conv_planes_mask(B * (calls if args.fold_time else 1), cfg["H"], cfg["W"], C, engine) == 7)
+                               planes=ops.conv_planes_mask(B * (calls if args.fold_time else 1), cfg["H"], cfg["W"], C, engine) == 7,
+                               heads=cfg["n_head"], M=cfg["slice_num"])
 
     out = {
         "metric": "ns64_train_samples_per_s", "value": round(world * B * args.steps / dt, 4), "unit": "samples/s",
@@ -484,6 +514,15 @@ def main():
         "final_loss_per_sample_call": round(float(loss) / B / calls, 5),
         "roofline": roof, "roofline_hbm": roof_hbm,
     }
+    if world > 1:
+        # what an N > 1 line needs to explain itself: the collective's device time (rank 0's HIP events around
+        # dist.all_reduce of the flat gradient bucket, mean over the timed steps; it runs after backward, not overlapped:
+        # with ten accumulating calls per iteration a parameter's gradient is final only in the last call's backward) and
+        # every rank's own step time
+        out["allreduce_ms"] = round(float(np.mean(ar_ms)), 3) if ar_ms else None
+        out["allreduce_gbs_per_rank"] = (round(2.0 * (world - 1) / world * sync.nbytes / (np.mean(ar_ms) * 1e-3) / 1e9, 1)
+                                         if ar_ms else None)
+        out["step_ms_per_rank"] = {"min": min(rank_ms), "max": max(rank_ms), "all": rank_ms} if rank_ms else None
 
     if not (args.fold_time or args.graph or args.no_folded_leg):
         # Secondary leg, reported next to (never instead of) `value`: the same iteration with its teacher-forced
@@ -512,7 +551,7 @@ def main():
         pool.enabled = True
         ed, _ = rk.timed(estep, esteps)
         pool.enabled = False
-        eroof, _ = rooflines(pool.drain_ms(), ops.ENGINE_F32, B * N, C)
+        eroof, _ = rooflines(pool.drain_ms(), ops.ENGINE_F32, B * N, C, heads=cfg["n_head"], M=cfg["slice_num"])
         out["fp32_exact_engine"] = {"value": round(world * B * esteps / ed, 4), "unit": "samples/s",
                                     "ms_per_step": round(1e3 * ed / esteps, 2), "steps": esteps, "roofline": eroof,
                                     "note": "every GEMM on v_mfma_f32_32x32x2_f32 (engine f32); same weights, data, loop"}
@@ -529,12 +568,16 @@ def main():
         for bsz, tag in ((B, f"b{B}"), (1, "b1")):
             gr = harness.GraphedRollout(model, x[:bsz], fx[:bsz])
             gr.run(fx[:bsz], 2)
-            d, _ = rk.timed(lambda: gr.run(fx[:bsz], 20), 1)
+            ds = sorted(rk.timed(lambda: gr.run(fx[:bsz], 20), 1)[0] for _ in range(args.rollout_repeats))
+            d = ds[len(ds) // 2]                                                  # median of the repeats
             out[f"rollout_steps_per_s_{tag}"] = round(20 / d, 2)                 # per replica
+            out[f"rollout_steps_per_s_{tag}_best"] = round(20 / ds[0], 2)
             out[f"rollout_frames_per_s_{tag}"] = round(world * 20 * bsz / d, 2)  # aggregate over all replicas
             if rank == 0:
-                log(f"rollout {tag}: {20 / d:.1f} steps/s per replica, {world * 20 * bsz / d:.0f} frames/s aggregate")
+                log(f"rollout {tag}: {20 / d:.1f} steps/s per replica (median of {len(ds)} 20-step rollouts, best "
+                    f"{20 / ds[0]:.1f}), {world * 20 * bsz / d:.0f} frames/s aggregate")
             del gr
+        out["rollout_sample"] = f"{args.rollout_repeats} timed 20-step graph-captured rollouts per batch size: median (and best)"
         model.train()
 
     if not args.no_darcy_leg:
@@ -542,6 +585,43 @@ def main():
         torch.cuda.empty_cache()
         out["darcy421"] = darcy_leg(rk, pool, engine, args.darcy_batch, min(max(args.steps, 3), 5))
         log(f"darcy421 leg: {out['darcy421']['ms_per_iter']} ms/iter, {out['darcy421']['value']} samples/s")
+
+    if engine != ops.ENGINE_BF16S and not (args.fold_time or args.graph or args.no_bf16_leg):
+        # Secondary leg: BASELINE configs[2] / [4] AS STATED — bf16.  The same exp_ns.py iteration (and the same Darcy
+        # iteration) on the bf16-STORAGE path (activations, saved tensors and inter-kernel gradients bf16 in HBM; fp32
+        # master weights, statistics and accumulators; optional bf16 gradient wire): a second model + optimizer on the
+        # same weights and this rank's shard, so an N > 1 run measures configs[2] next to the fp32-accurate `value`.
+        ops.event_provider = pool.provider
+        torch.cuda.empty_cache()
+        mb = harness.build_model(cfg, sd, dev, engine="bf16s").train()
+        ob = FusedAdamW(mb.parameters(), lr=1e-3, weight_decay=1e-5, grad_comm_dtype=torch.bfloat16)
+        lb = FusedTestLoss(size_average=False)
+
+        def bstep():
+            return harness.train_step(mb, ob, None, x, fx, yy, grad_sync=ob.sync, loss_fn=lb)
+        bstep()
+        bsteps = min(args.steps, 8)
+        pool.enabled = True
+        ob.sync.timing = world > 1
+        bd, (bloss, _) = rk.timed(bstep, bsteps)
+        pool.enabled = False
+        bar = ob.sync.drain_allreduce_ms() if world > 1 else []
+        broof, bhbm = rooflines(pool.drain_ms(), ops.ENGINE_BF16S, B * N, C, heads=cfg["n_head"], M=cfg["slice_num"])
+        leg = {"workload": f"the same exp_ns.py iteration, batch {B}/GPU, {ENGINE_LABEL[ops.ENGINE_BF16S]}; bf16 gradient "
+                           "wire (BASELINE configs[2] as stated)",
+               "value": round(world * B * bsteps / bd, 4), "unit": "samples/s", "ms_per_step": round(1e3 * bd / bsteps, 2),
+               "steps": bsteps, "dtype": "bf16", "global_batch": world * B, "grad_allreduce_bytes": ob.sync.nbytes,
+               "final_loss_per_sample_call": round(float(bloss) / B / calls, 5), "roofline": broof, "roofline_hbm": bhbm}
+        if world > 1:
+            leg["allreduce_ms"] = round(float(np.mean(bar)), 3) if bar else None
+            leg["step_ms_per_rank"] = {"min": min(rk.last_rank_ms), "max": max(rk.last_rank_ms)} if rk.last_rank_ms else None
+        del mb, ob
+        torch.cuda.empty_cache()
+        if not args.no_darcy_leg:
+            leg["darcy421"] = darcy_leg(rk, pool, ops.ENGINE_BF16S, args.darcy_batch, min(max(args.steps, 3), 5))
+        out["bf16_storage"] = leg
+        log(f"bf16-storage leg: {leg['value']} samples/s"
+            + (f", darcy421 {leg['darcy421']['ms_per_iter']} ms/iter" if "darcy421" in leg else ""))
 
     ops.event_provider = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

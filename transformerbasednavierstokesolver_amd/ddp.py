@@ -142,13 +142,34 @@ class FlatGradSync:
     def __call__(self):
         self.adopt()
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            ev = None
+            if getattr(self, "timing", False) and self.flat.is_cuda:      # bench: device time of the collective (+ wire casts)
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
             if self.comm_dtype is not None and self.comm_dtype != self.flat.dtype:
                 wire = self.flat.to(self.comm_dtype)
                 dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group)
                 self.flat.copy_(wire)
             else:
                 dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            if ev is not None:
+                ev[1].record()
+                self._events.append(ev)
         self.release_untouched()
+
+    timing = False
+
+    @property
+    def _events(self):
+        if not hasattr(self, "_ev_list"):
+            self._ev_list = []
+        return self._ev_list
+
+    def drain_allreduce_ms(self):
+        """Device-side durations (ms) of the all-reduces issued since the last call, `timing` enabled (synchronize first)."""
+        out = [a.elapsed_time(b) for a, b in self._events]
+        self._ev_list = []
+        return out
 
     @property
     def nbytes(self):
