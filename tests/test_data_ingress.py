@@ -63,3 +63,49 @@ def test_ns_generator_invariants():
     assert torch.allclose(out.double().mean(dim=(1, 2)), w0.double().mean(dim=(1, 2))[:, None].expand(2, 4), atol=1e-6)
     again = data.simulate_ns_vorticity(w0, visc=1e-3, T=0.2, dt=1e-3, record=4, forcing=False)
     assert torch.equal(out, again)
+
+
+# ---------------------------------------------------------------------------------------------- against the oracle
+def _ns_array(S=9, T=20, seed=11):
+    return synth.synth_ns_fields(S, 64, 64, T, seed=seed)
+
+
+@pytest.mark.parametrize("r", [1, 2, 3, 7])          # 7: the `[:, :h, :h]` cut of exp_ns.py:67 actually trims
+def test_ns_split_and_positions_match_the_oracle_restatement(r):
+    """data.split_ns_trajectories / grid_positions against oracle/data_oracle.py (exp_ns.py:61-94 restated statement by
+    statement in numpy): bit-exact, including the last-`ntest` test split and the 'xy' meshgrid axis order."""
+    from oracle import data_oracle as dorc
+    u = _ns_array()
+    got = data.split_ns_trajectories(u, ntrain=5, ntest=3, T_in=10, T=10, r=r)
+    want = dorc.ns_split(u, 5, 3, 10, 10, r)
+    assert got["h"] == want["h"]
+    for k in ("train_a", "train_u", "test_a", "test_u"):
+        assert got[k].dtype == torch.float32 and np.array_equal(got[k].numpy(), want[k]), k
+    pos = data.grid_positions(want["h"])
+    assert np.array_equal(pos.repeat(5, 1, 1).numpy(), dorc.ns_positions(want["h"], 5))
+    # the first coordinate varies along image COLUMNS (np.meshgrid 'xy'), unlike Model.get_grid (SURVEY A.3)
+    h = want["h"]
+    if h > 1:
+        assert pos[0, 1, 0] > pos[0, 0, 0] and pos[0, 1, 1] == pos[0, 0, 1] and pos[0, h, 1] > pos[0, 0, 1]
+
+
+@pytest.mark.parametrize("r", [1, 5, 20])
+def test_darcy_split_and_unit_transformer_match_the_oracle_restatement(r):
+    """data.split_darcy + UnitTransformer against the restatement of exp_darcy.py:71-96 / utils/normalizer.py:30-48."""
+    from oracle import data_oracle as dorc
+    from transformerbasednavierstokesolver_amd.utils.normalizer import UnitTransformer
+    rng = np.random.default_rng(5)
+    coeff = rng.choice([3.0, 12.0], size=(4, 421, 421))
+    sol = rng.standard_normal((4, 421, 421)) * 0.01
+    x, y, s = data.split_darcy(coeff, sol, 3, r)
+    xo, yo, so, dx = dorc.darcy_split(coeff, sol, 3, r)
+    assert s == so and abs(dx - 1.0 / s) == 0.0
+    assert x.dtype == torch.float32 and y.dtype == torch.float64
+    assert np.array_equal(x.numpy(), xo) and np.array_equal(y.numpy(), yo)
+    for t, to in ((x, xo), (y, yo)):
+        un = UnitTransformer(t)
+        mean, std = dorc.unit_fit(to.astype(np.float64))
+        assert np.allclose(un.mean.double().numpy(), mean, rtol=1e-6) and np.allclose(un.std.double().numpy(), std, rtol=2e-6)
+        enc = un.encode(t)
+        assert np.allclose(enc.double().numpy(), dorc.unit_encode(to.astype(np.float64), mean, std), rtol=1e-4, atol=1e-5)
+        assert np.allclose(un.decode(enc).double().numpy(), to, rtol=1e-5, atol=1e-6)

@@ -171,6 +171,14 @@ def test_darcy_421_full_depth_8_layers_bf16_compute(oracle_on_gpu):
     _darcy_full_depth(oracle_on_gpu, "bf16", fwd_tol=3e-2, loss_tol=3e-2, grad_tol=0.2, qk_tol=1.0, softmax_tol=0.5)
 
 
+def test_darcy_421_full_depth_8_layers_bf16_storage(oracle_on_gpu):
+    """BASELINE configs[4] AS STATED (exp_darcy.py:118-130,209-234: 421 x 421, 8 layers, C=128, M=128, bf16): the bf16-STORAGE
+    path (engine "bf16s": activations, saved tensors and inter-kernel gradients bf16 in HBM, fp32 master weights / statistics /
+    accumulators) through all eight layers against the fp64 oracle.  SURVEY 8c bf16 tolerance: forward <= 3e-2; gradients
+    carry eight layers of bf16 activation rounding (same bounds as the bf16-compute test)."""
+    _darcy_full_depth(oracle_on_gpu, "bf16s", fwd_tol=3e-2, loss_tol=3e-2, grad_tol=0.2, qk_tol=1.0, softmax_tol=0.5)
+
+
 def _model_vs_oracle(orc, cfg, seed, B, fx_dim, T=None, fwd_tol=1e-5):
     """full Model forward+backward against the fp64 oracle evaluated on the GPU."""
     from transformerbasednavierstokesolver_amd import synth, harness

@@ -64,3 +64,33 @@ def test_ns_generator_on_the_gpu_matches_the_cpu_run():
     # and the generated frames are a valid exp_ns input: split + one model call on the device
     sp = data.split_ns_trajectories(gpu.cpu().numpy(), ntrain=2, ntest=1, T_in=3, T=2)
     assert sp["train_a"].shape == (2, 4096, 3) and sp["test_u"].shape == (1, 4096, 2)
+
+
+def test_resident_split_on_the_device_equals_the_oracle_restatement():
+    """The device-resident split (what the training loop actually reads) against oracle/data_oracle.py — the restatement of
+    exp_ns.py:61-94 and exp_darcy.py:71-96 — not against the host copy of the same product code: bit-exact for the slicing
+    and the positions, fp32 rounding for the UnitTransformer encode evaluated on the GPU."""
+    from oracle import data_oracle as dorc
+    from transformerbasednavierstokesolver_amd.utils.normalizer import UnitTransformer
+    u = synth.synth_ns_fields(8, 64, 64, 20, seed=21)
+    for r in (1, 2):
+        want = dorc.ns_split(u, 5, 2, 10, 10, r)
+        sp = data.split_ns_trajectories(u, ntrain=5, ntest=2, T_in=10, T=10, r=r)
+        ds = data.ResidentDataset(data.grid_positions(sp["h"]).repeat(5, 1, 1), sp["train_a"], sp["train_u"], device=DEV)
+        got = [t.cpu().numpy() for t in next(iter(ds.batches(5)))]
+        assert np.array_equal(got[0], dorc.ns_positions(want["h"], 5))
+        assert np.array_equal(got[1], want["train_a"]) and np.array_equal(got[2], want["train_u"])
+        te = data.ResidentDataset(sp["test_a"], sp["test_u"], device=DEV)
+        assert np.array_equal(te.tensors[0].cpu().numpy(), want["test_a"]) and np.array_equal(te.tensors[1].cpu().numpy(), want["test_u"])
+    rng = np.random.default_rng(9)
+    coeff, sol = rng.choice([3.0, 12.0], size=(3, 421, 421)), rng.standard_normal((3, 421, 421)) * 0.01
+    x, y, s = data.split_darcy(coeff, sol, 3, 5)
+    xo, yo, so, _ = dorc.darcy_split(coeff, sol, 3, 5)
+    assert s == so
+    xd, yd = x.to(DEV), y.to(DEV)
+    xn, yn = UnitTransformer(xd), UnitTransformer(yd)              # fitted and applied on the device
+    mx, sx = dorc.unit_fit(xo.astype(np.float64))
+    my, sy = dorc.unit_fit(yo)
+    assert rel_l2(xn.encode(xd), dorc.unit_encode(xo.astype(np.float64), mx, sx)) < 1e-5
+    assert rel_l2(yn.encode(yd), dorc.unit_encode(yo, my, sy)) < 1e-12
+    assert rel_l2(yn.decode(yn.encode(yd)), yo) < 1e-12
