@@ -74,8 +74,8 @@ def slice_kernel_names(engine, D, M, planes):
                 "slice_bwd": f"slice_bwd_kernel<{D}, {mt}, float, 0>"}
     t = "__bf16" if engine == ops.ENGINE_BF16S else "float"
     pl = (3 if engine == ops.ENGINE_SPLIT else 1) if planes and engine != ops.ENGINE_BF16S else 0
-    # fp32 storage with M = 128: the backward stays on the fp32-MFMA kernel (pa2d_slice3_bwd.hip)
-    bwd = f"slice_bwd_kernel<{D}, {mt}, float, {pl}>" if (mt == 8 and t == "float") else f"slice_bwd3_kernel<{D}, {mt}, {t}, {pl}>"
+    # M = 128 with D != 16: the backward stays on the fp32-MFMA kernel (pa2d_slice3_bwd.hip)
+    bwd = f"slice_bwd_kernel<{D}, {mt}, {t}, {pl}>" if (mt == 8 and D != 16) else f"slice_bwd3_kernel<{D}, {mt}, {t}, {pl}>"
     return {"slice_scatter": f"scatter3_kernel<{D}, {mt}, {t}>", "deslice": f"deslice3_kernel<{D}, {mt}, {t}>", "slice_bwd": bwd}
 
 

@@ -145,20 +145,25 @@ __device__ __forceinline__ bf16x8 tr_frag(const unsigned char* a0, const unsigne
 __device__ __forceinline__ constexpr int swz(int row) { return 3 * ((row >> 2) & 1); }
 
 template <int D, int MT> struct BwCfg {
+    static constexpr bool K16 = D == 16;            // K-packed contractions over d (two plane pairs per MFMA), see below
     static constexpr int KST = (D + 31) / 32;       // 32-wide k-steps of a contraction over d
-    static constexpr int KP = 32 * KST;             // d extent of the parameter images (zero padded)
+    static constexpr int KP = K16 ? 16 : 32 * KST;  // d extent of the parameter images (zero padded unless K16)
     static constexpr int DT = (D + 15) / 16;        // 16-wide tiles over d
     static constexpr int DP = 16 * DT;
     static constexpr int MU = (MT + 1) / 2;         // 32-slice k-steps of a contraction over the slices
     static constexpr int MP = 32 * MU;              // slice extent of the images (zero padded)
     static constexpr bool SWZ = KP == 32;           // 64-byte image rows, 16-byte chunk c stored at c ^ swz(row)
-    static constexpr int RP = SWZ ? KP : KP + 8;    // image row pitch (elements)
+    static constexpr int RP = (SWZ || K16) ? KP : KP + 8;    // image row pitch (elements); K16: 32-byte rows, conflict-free as is
     static constexpr int PIMG = MP * RP * 2;        // bytes of one plane image
-    static constexpr int XP = KP + 16;              // row pitch of the X scratch [16 points][d]: 96 B rows at D = 32
+    static constexpr int XP = K16 ? 16 : KP + 16;   // row pitch of the X scratch [16 points][d]: 96 B rows at D = 32, 32 B at D = 16
     static constexpr int LP = MP + 16;              // row pitch of the dL scratch [16 points][slices]: 160 B rows at M = 64
     static constexpr int SCR = 3 * 16 * (XP > LP ? XP : LP) * 2;      // scratch bytes per wave (X and dL alias)
     static constexpr int IMGS = 9 * PIMG;                             // Ws, O, dS x 3 planes
-    static constexpr int SMEM = IMGS + 2 * MP * 4 + 4 * SCR;          // + bs, dn (fp32)
+    // M = 128: z, dW, W, the dbs and dWs accumulators alone are 160 registers per lane: the kernel needs more than the 256 of
+    // two waves per SIMD (134 spilled registers measured), so it runs ONE wave per SIMD: 4 waves, one workgroup per CU
+    static constexpr int WAVES = 4;
+    static constexpr int WPS = MT == 8 ? 1 : 2;     // waves per SIMD the register budget is sized for
+    static constexpr int SMEM = IMGS + 2 * MP * 4 + WAVES * SCR;      // + bs, dn (fp32)
 };
 
 struct SliceBwd3Params {
@@ -179,10 +184,17 @@ struct SliceBwd3Params {
 
 }  // namespace
 
-// one workgroup (4 waves) = one (batch, head, point chunk); wave w takes the groups of 32 points w, w + 4, ...
+// one workgroup (4 waves; 8 at M = 128) = one (batch, head, point chunk); wave w takes the groups of 32 points w, w + WAVES, ...
+//
+// D = 16: a contraction over d fills half of the MFMA's k index, so the other half carries a second plane pair (as in
+// pa2d_slice3.hip): parameter fragment [pa | pb] x activation fragment [xa | xb] with lanes kq < 2 holding member "a" at
+// d = 8 kq .., lanes kq >= 2 member "b" at d = 8 (kq - 2) ..; fp32 storage: ([w0|w0],[x0|x1]) ([w1|w0],[x0|x2])
+// ([w1|w2],[x1|x0]); bf16 storage: ([w0|w1],[x0|x0]) ([w2|-],[x0|0]).
 template <int D, int MT, typename T, int PL>
-__global__ __launch_bounds__(256, 2) void slice_bwd3_kernel(const SliceBwd3Params p) {
+__global__ __launch_bounds__(256, MT == 8 ? 1 : 2) void slice_bwd3_kernel(const SliceBwd3Params p) {
     using C = BwCfg<D, MT>;
+    constexpr bool K16 = C::K16;
+    constexpr int NTH = 64 * C::WAVES;
     constexpr int KST = C::KST, DT = C::DT, MU = C::MU, MP = C::MP, DP = C::DP, RP = C::RP, PIMG = C::PIMG;
     constexpr int XP = C::XP, LP = C::LP;
     constexpr int NA = Planes<T>::ACT, NW = Planes<T>::WGT;
@@ -200,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void slice_bwd3_kernel(const SliceBwd3Param
     const size_t bh = (size_t)(b * p.heads + hh);
 
     // ---- parameter images: thread -> (slice m, 8 consecutive d) pieces of Ws, O, dS, split into 3 planes
-    for (int i = tid; i < MP * (C::KP / 8); i += 256) {
+    for (int i = tid; i < MP * (C::KP / 8); i += NTH) {
         const int m = i / (C::KP / 8), d0 = 8 * (i % (C::KP / 8));
         const float* src[3] = {p.ws + (size_t)m * D, p.o + (bh * p.M + m) * D, p.ds + (bh * p.M + m) * D};
 #pragma unroll
@@ -215,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void slice_bwd3_kernel(const SliceBwd3Param
                 *reinterpret_cast<bf16x8*>(img + (mat * 3 + q) * PIMG + m * RP * 2 + (C::SWZ ? ((d0 >> 3) ^ swz(m)) * 16 : d0 * 2)) = pl[q];
         }
     }
-    for (int i = tid; i < MP; i += 256) {
+    for (int i = tid; i < MP; i += NTH) {
         bsL[i] = i < p.M ? p.bs[i] : NEG_BIG;          // padding slices: weight exactly 0
         dnL[i] = i < p.M ? p.dn[bh * p.M + i] : 0.f;
     }
@@ -223,14 +235,22 @@ __global__ __launch_bounds__(256, 2) void slice_bwd3_kernel(const SliceBwd3Param
 
     // lane-constant LDS byte offsets
     // row fragment (A operand, row = slice 16 mt + li, k = d 32 s + 8 kq ..): + mt * 16 * RP * 2 + s * 64
-    const unsigned rowf = (unsigned)(li * RP * 2 + (C::SWZ ? (kq ^ swz(li)) * 16 : 8 * kq * 2));
+    const unsigned rowf = (unsigned)(li * RP * 2 + (K16 ? (kq & 1) * 16 : (C::SWZ ? (kq ^ swz(li)) * 16 : 8 * kq * 2)));
+    // K16: which plane image a lane reads for K-packed term c (0..NC-1)
+    constexpr int NA_ = Planes<T>::ACT, NC = NA_ == 3 ? 3 : 2;
+    unsigned pk16[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        const int pa = NA_ == 3 ? (c == 0 ? 0 : 1) : (c == 0 ? 0 : 2), pb = NA_ == 3 ? (c == 2 ? 2 : 0) : (c == 0 ? 1 : 2);
+        pk16[c] = (unsigned)((kq < 2 ? pa : pb) * PIMG);
+    }
     // transposed fragment of an image (A operand, row = channel 16 dt + li, k-slot e of lane group kq = slice
     // 32 u + 4 kq + e (e < 4) or 32 u + 16 + 4 kq + e - 4): block rows m0 = 32 u + 4 kq (+ 16), lane 4 q + pq of the
     // group supplies row m0 + q, columns 16 dt + 4 pq ..: + u * 32 * RP * 2 + dt * 32 (+ 16 * RP * 2 for the second read)
     const int q4 = li >> 2, pq = li & 3;
-    const unsigned trf = (unsigned)((4 * kq + q4) * RP * 2 + (C::SWZ ? 0 : 4 * pq * 2));
+    const unsigned trf = (unsigned)((4 * kq + q4) * RP * 2 + ((C::SWZ && !K16) ? 0 : 4 * pq * 2));
     // SWZ: the 8-byte piece (chunk 2 dt + (pq >> 1), half pq & 1) of a row with swizzle 3 * (kq & 1)
-    auto trc = [&](int dt) -> unsigned { return C::SWZ ? (unsigned)((((2 * dt + (pq >> 1)) ^ (3 * (kq & 1))) * 16) + 8 * (pq & 1)) : (unsigned)(dt * 32); };
+    auto trc = [&](int dt) -> unsigned { return (C::SWZ && !K16) ? (unsigned)((((2 * dt + (pq >> 1)) ^ (3 * (kq & 1))) * 16) + 8 * (pq & 1)) : (unsigned)(dt * 32); };
     // transposed HALF fragments of the per-tile scratch images: the contraction over the 32 points of a group uses the
     // k order (element e of lane group kq) = point 4 kq + e of tile 0 for e < 4, point 4 kq + e - 4 of tile 1 otherwise,
     // so each tile contributes one transposed read (rows 4 kq + q, columns 4 pq ..) per fragment
@@ -267,8 +287,8 @@ __global__ __launch_bounds__(256, 2) void slice_bwd3_kernel(const SliceBwd3Param
         const bool ok_ = pt_ < p_end;
 #pragma unroll
         for (int s = 0; s < KST; ++s) {
-            const bool okd_ = 32 * s + 8 * kq < D;
-            const unsigned c_ = hcol + (32 * s + 8 * kq) * ES;
+            const bool okd_ = K16 || 32 * s + 8 * kq < D;
+            const unsigned c_ = hcol + (K16 ? 8 * (kq & 1) : 32 * s + 8 * kq) * ES;
             load_raw8<T>(rx, (ok_ && okd_) ? (row0 + pt_) * ldxb + c_ : OOB_OFF, xr[s]);
             load_raw8<T>(rf, (ok_ && okd_) ? (row0 + pt_) * ldfb + c_ : OOB_OFF, fr[s]);
             load_raw8<T>(rg, (ok_ && okd_) ? (row0 + pt_) * ldgb + c_ : OOB_OFF, gr[s]);
@@ -282,7 +302,7 @@ __global__ __launch_bounds__(256, 2) void slice_bwd3_kernel(const SliceBwd3Param
 
     int g = p_begin + wave * 32;
     if (g < p_end) load_tile(g);
-    for (; g < p_end; g += 128) {
+    for (; g < p_end; g += 32 * C::WAVES) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int pt = g + 16 * t + li;
@@ -298,6 +318,41 @@ __global__ __launch_bounds__(256, 2) void slice_bwd3_kernel(const SliceBwd3Param
                 dw[mt] = *reinterpret_cast<const f32x4*>(dnL + 16 * mt + 4 * kq);
             }
             auto row_product = [&](int mat, const bf16x8 (&bpl)[KST][NA], f32x4 (&acc)[MT]) {
+                if constexpr (K16) {
+                    // activation side of the K-packed terms: [x0|x1] [x0|x2] [x1|x0]   (bf16 storage: [x0|x0] [x0|0])
+                    bf16x8 xc[NC];
+                    {
+                        const bool lo = kq < 2;
+                        const u32x4 x0 = __builtin_bit_cast(u32x4, bpl[0][0]);
+                        if constexpr (NA == 3) {
+                            const u32x4 x1 = __builtin_bit_cast(u32x4, bpl[0][1]), x2 = __builtin_bit_cast(u32x4, bpl[0][NA - 1]);
+                            u32x4 c0, c1, c2;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) { c0[i] = lo ? x0[i] : x1[i]; c1[i] = lo ? x0[i] : x2[i]; c2[i] = lo ? x1[i] : x0[i]; }
+                            xc[0] = __builtin_bit_cast(bf16x8, c0); xc[1] = __builtin_bit_cast(bf16x8, c1); xc[NC - 1] = __builtin_bit_cast(bf16x8, c2);
+                        } else {
+                            u32x4 c1;
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) c1[i] = lo ? x0[i] : 0u;
+                            xc[0] = bpl[0][0]; xc[1] = __builtin_bit_cast(bf16x8, c1);
+                        }
+                    }
+                    bf16x8 fr_[2][NC];
+#pragma unroll
+                    for (int c = 0; c < NC; ++c) fr_[0][c] = *reinterpret_cast<const bf16x8*>(img + mat * 3 * PIMG + pk16[c] + rowf);
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) {
+                        if (mt + 1 < MT) {
+#pragma unroll
+                            for (int c = 0; c < NC; ++c)
+                                fr_[(mt + 1) & 1][c] = *reinterpret_cast<const bf16x8*>(img + mat * 3 * PIMG + pk16[c] + rowf +
+                                                                                       (unsigned)((mt + 1) * 16 * RP * 2));
+                        }
+#pragma unroll
+                        for (int c = NC - 1; c >= 0; --c) acc[mt] = mfma_bf(fr_[mt & 1][c], xc[c], acc[mt]);
+                        S3B_BARRIER
+                    }
+                } else {
                 bf16x8 fr_[2][3];
 #pragma unroll
                 for (int q = 0; q < 3; ++q) fr_[0][q] = *reinterpret_cast<const bf16x8*>(img + (mat * 3 + q) * PIMG + rowf);
@@ -314,6 +369,7 @@ __global__ __launch_bounds__(256, 2) void slice_bwd3_kernel(const SliceBwd3Param
                     acc[mt] = mfma_terms<3, NA>(fr_[i & 1], bpl[s_], acc[mt]);
                     S3B_BARRIER
                 }
+                }
             };
             {
                 bf16x8 xpl[KST][NA];
@@ -322,7 +378,7 @@ __global__ __launch_bounds__(256, 2) void slice_bwd3_kernel(const SliceBwd3Param
                     raw_planes<T>(xr[s], xpl[s]);
 #pragma unroll
                     for (int q = 0; q < NA; ++q)
-                        *reinterpret_cast<bf16x8*>(scr + q * 16 * XP * 2 + (li * XP + 32 * s + 8 * kq) * 2) = xpl[s][q];
+                        *reinterpret_cast<bf16x8*>(scr + q * 16 * XP * 2 + (li * XP + (K16 ? 8 * (kq & 1) : 32 * s + 8 * kq)) * 2) = xpl[s][q];
                 }
                 row_product(0, xpl, z);
             }
@@ -344,7 +400,7 @@ __global__ __launch_bounds__(256, 2) void slice_bwd3_kernel(const SliceBwd3Param
 #pragma unroll
                 for (int s = 0; s < KST; ++s) raw_planes<T>(fr[s], fpl[s]);
                 {   // next tile: t = 0 -> second tile of this group, t = 1 -> first tile of the wave's next group
-                    const int gn = t == 0 ? g + 16 : g + 128;
+                    const int gn = t == 0 ? g + 16 : g + 32 * C::WAVES;
                     if (gn < p_end) load_tile(gn);
                 }
                 row_product(2, fpl, dw);
@@ -582,7 +638,7 @@ __global__ __launch_bounds__(256, 2) void slice_bwd3_kernel(const SliceBwd3Param
     float* const rT = rB + 16 * MT;
     static_assert((16 * MT * DP + 16 * MT + 4) * 4 <= C::IMGS, "reduction scratch must fit in the image region");
     __syncthreads();
-    for (int wv = 0; wv < 4; ++wv) {
+    for (int wv = 0; wv < C::WAVES; ++wv) {
         if (wave == wv) {
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
@@ -601,14 +657,14 @@ __global__ __launch_bounds__(256, 2) void slice_bwd3_kernel(const SliceBwd3Param
         __syncthreads();
     }
     float* po = p.part + (size_t)bid * p.stride;
-    for (int i = tid; i < p.M * D; i += 256) po[i] = rW[(i / D) * DP + (i % D)] * inv_tau;
-    for (int i = tid; i < p.M; i += 256) po[p.M * D + i] = rB[i] * inv_tau;
+    for (int i = tid; i < p.M * D; i += NTH) po[i] = rW[(i / D) * DP + (i % D)] * inv_tau;
+    for (int i = tid; i < p.M; i += NTH) po[p.M * D + i] = rB[i] * inv_tau;
     if (tid == 0) po[p.M * D + p.M] = -rT[0] * inv_tau * inv_tau;
     if constexpr (PL != 0) {
         // conv bias gradients = column sums of dX | dF over the points, from token-level identities (no per-point sums):
         //   sum_n dX[n][d] = sum_m (sum_n dL[n][m] / tau) Ws[m][d]     — this block's dbs partial
         //   sum_n dF[n][d] = sum_m (sum_n W[n][m]) dS[m][d] = sum_m nrm[m] dS[m][d]   — whole (batch, head): chunk 0 only
-        for (int i = tid; i < 2 * D; i += 256) {
+        for (int i = tid; i < 2 * D; i += NTH) {
             float v = 0.f;
             if (i < D) {
                 for (int m = 0; m < p.M; ++m) v = fmaf(rB[m] * inv_tau, p.ws[(size_t)m * D + i], v);
@@ -626,12 +682,12 @@ static int launch_bwd3_one(const SliceBwd3Params& p, int grid, hipStream_t st) {
     constexpr int smem = BwCfg<D, MT>::SMEM;
     // not built for these shapes: the caller keeps the fp32-MFMA kernel.  (D = 64, M = 128) does not fit the LDS; M = 128 with
     // fp32 storage needs more than 256 registers here (spills: measured 1.57 ms against 1.14 ms at Darcy 421^2)
-    if constexpr (smem > 160 * 1024 || (MT == 8 && sizeof(T) == 4)) return PA2D_ERR_UNSUPPORTED;
+    if constexpr (smem > 160 * 1024 || (MT == 8 && D != 16)) return PA2D_ERR_UNSUPPORTED;
     else {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&slice_bwd3_kernel<D, MT, T, PL>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, smem);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((slice_bwd3_kernel<D, MT, T, PL>), dim3(slice_grid(grid)), dim3(256), smem, st, p);
+    hipLaunchKernelGGL((slice_bwd3_kernel<D, MT, T, PL>), dim3(slice_grid(grid)), dim3(64 * BwCfg<D, MT>::WAVES), smem, st, p);
     return PA2D_OK;
     }
 }
