@@ -297,6 +297,16 @@ int launch_kc_split(KCParams& p, bool im2col, hipStream_t st) {
         }
         const dim3 gbig(ceil_div(p.M / 256, 8) * 8 * tiles_n);
         hipLaunchKernelGGL((gemm_kc_split_kernel<256, 128, true, 3, true>), gbig, dim3(512), smem_big, st, p);
+    } else if (im2col && !bf && (long long)tiles_m * tiles_n < 256) {
+        // small launches (rollout at batch 1: 32 x 4 tiles of 128 x 128 leave half of the 256 CUs idle): 64-row tiles
+        const int smem_s = 2 * (64 + 128) * 208;
+        {
+            hipError_t es = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kc_split_kernel<64, 128, true, 3, true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, smem_s);
+            if (es != hipSuccess) return (int)es;
+        }
+        const dim3 gs(ceil_div(ceil_div(p.M, 64), 8) * 8 * tiles_n);
+        hipLaunchKernelGGL((gemm_kc_split_kernel<64, 128, true, 3, true>), gs, dim3(512), smem_s, st, p);
     } else
     if (!im2col) hipLaunchKernelGGL((gemm_kc_split_kernel<128, 128, false, 1, false>), grid, dim3(512), smem, st, p);
     else if (bf) hipLaunchKernelGGL((gemm_kc_split_kernel<128, 128, true, 1, true>), grid, dim3(512), smem, st, p);

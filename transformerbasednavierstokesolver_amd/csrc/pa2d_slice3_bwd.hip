@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256, MT == 8 ? 1 : 2) void slice_bwd3_kernel(const 
     // k order (element e of lane group kq) = point 4 kq + e of tile 0 for e < 4, point 4 kq + e - 4 of tile 1 otherwise,
     // so each tile contributes one transposed read (rows 4 kq + q, columns 4 pq ..) per fragment
     const unsigned trx = (unsigned)(((4 * kq + q4) * XP + 4 * pq) * 2);
-    const unsigned trl = (unsigned)(((4 * kq + q4) * LP + 4 * pq) * 2);
+    const unsigned trl = (unsigned)(((4 * kq + q4) * LP + 4 * pq) * 2 + (kq >> 1) * 16);
 
     f32x4 wsacc[MT][DT];
     float dbacc[MT][4];
@@ -500,7 +500,9 @@ __global__ __launch_bounds__(256, MT == 8 ? 1 : 2) void slice_bwd3_kernel(const 
 #pragma unroll
                     for (int q = 0; q < NW; ++q) {
                         const u32x4 v = __builtin_bit_cast(u32x4, dlp[u][q]);
-                        unsigned char* r_ = scr + q * 16 * LP * 2 + li * LP * 2 + (32 * u) * 2;
+                        // rows 8..15 sit 16 bytes to the right: the 8-byte writes of 16 rows and the transposed 4-row block reads
+                        // are then both bank-conflict free on the 160-byte pitch
+                        unsigned char* r_ = scr + q * 16 * LP * 2 + li * LP * 2 + (li >> 3) * 16 + (32 * u) * 2;
                         *reinterpret_cast<u32x2*>(r_ + (4 * kq) * 2) = (u32x2){v.x, v.y};
                         *reinterpret_cast<u32x2*>(r_ + (16 + 4 * kq) * 2) = (u32x2){v.z, v.w};
                     }
