@@ -99,16 +99,28 @@ __device__ __forceinline__ void kc_epilogue(const KCParams& p, f32x16 (&acc)[TM]
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 
+// Exact split x = hi + mid + lo (up to 2^-25 |x|) of four floats into three bf16 planes.  Written on the PACKED conversion
+// result: the straightforward scalar form makes hipcc convert every element a second time on its own to build the residual
+// (7.5 instructions per element); per pair this is 3 v_cvt_pk_bf16_f32 + 2 x (v_lshlrev, v_and, v_pk_add_f32) = 4.5.
 __device__ __forceinline__ void split3(const float4 v, bf16x4& hi, bf16x4& mid, bf16x4& lo) {
-    const float xs[4] = {v.x, v.y, v.z, v.w};
+    typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+    typedef float f32x2_ __attribute__((ext_vector_type(2)));
+    typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
+    const f32x2_ a[2] = {{v.x, v.y}, {v.z, v.w}};
+    u32x2_ ph, pm, pl;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const __bf16 h = (__bf16)xs[i];
-        const float r1 = xs[i] - (float)h;
-        const __bf16 m = (__bf16)r1;
-        const float r2 = r1 - (float)m;
-        hi[i] = h; mid[i] = m; lo[i] = (__bf16)r2;
+    for (int q = 0; q < 2; ++q) {
+        const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(a[q], bf16x2_));
+        const f32x2_ hf = {__uint_as_float(h << 16), __uint_as_float(h & 0xffff0000u)};
+        const f32x2_ r1 = a[q] - hf;
+        const unsigned m = __builtin_bit_cast(unsigned, __builtin_convertvector(r1, bf16x2_));
+        const f32x2_ mf = {__uint_as_float(m << 16), __uint_as_float(m & 0xffff0000u)};
+        const unsigned l = __builtin_bit_cast(unsigned, __builtin_convertvector(r1 - mf, bf16x2_));
+        ph[q] = h; pm[q] = m; pl[q] = l;
     }
+    hi = __builtin_bit_cast(bf16x4, ph);
+    mid = __builtin_bit_cast(bf16x4, pm);
+    lo = __builtin_bit_cast(bf16x4, pl);
 }
 
 struct MCParams {
