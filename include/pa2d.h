@@ -71,15 +71,23 @@ int pa2d_layernorm_bwd(const float* dy, const float* x, const float* mean, const
 
 /* ---- dense layers: nn.Linear of MLP (…_2D.py:26-38), to_out (Physics_Attention.py:81-84,119)
  * y[M,N] = act(x[M,K] . w[N,K]^T + bias) (+ res);  pre (optional) receives the pre-activation.
- * Requires K % 4 == 0 and ldx, ldw % 4 == 0. */
+ * Requires K % 4 == 0 and ldx, ldw % 4 == 0.
+ * ws / ws_bytes: optional scratch (NULL / 0 allowed).  With pa2d_gemm_fwd_workspace(N, K, engine) bytes the split
+ * engine's large-M layers (K in {128, 256}, N % 64 == 0, M >= 32768) run on the row-stationary kernel, which reads
+ * the weight as a bf16 plane image made in ws by this call; results do not depend on which kernel ran beyond fp32
+ * summation order. */
+size_t pa2d_gemm_fwd_workspace(int N, int K, int engine);
 int pa2d_gemm_bias_act_fwd(const float* x, long long ldx, const float* w, long long ldw, const float* bias,
                            const float* res, long long ldres, float* y, long long ldy, float* pre,
-                           long long ldpre, int M, int N, int K, int act, int engine, pa2d_stream_t stream);
+                           long long ldpre, void* ws, size_t ws_bytes, int M, int N, int K, int act, int engine,
+                           pa2d_stream_t stream);
 /* dx[M,K] = (dy[M,N] . w[N,K]) * act'(pre[M,K])  (pre NULL -> no activation factor);
- * wt_ws: K*N floats scratch (transposed weight). */
+ * ws: at least K*N floats (transposed weight; PA2D_ERR_WORKSPACE below that); pa2d_gemm_bwd_data_workspace(N, K,
+ * engine) bytes also hold the weight plane image of the row-stationary kernel (as for the forward). */
+size_t pa2d_gemm_bwd_data_workspace(int N, int K, int engine);
 int pa2d_gemm_bwd_data(const float* dy, long long lddy, const float* w, long long ldw, const float* pre,
-                       long long ldpre, int act, float* dx, long long lddx, float* wt_ws, int M, int N, int K,
-                       int engine, pa2d_stream_t stream);
+                       long long ldpre, int act, float* dx, long long lddx, void* ws, size_t ws_bytes, int M, int N,
+                       int K, int engine, pa2d_stream_t stream);
 size_t pa2d_gemm_bwd_weight_workspace(int M, int N, int K, int engine);
 /* dw[N,K] (+)= dy[M,N]^T . x[M,K];  db[N] (+)= column sums of dy (db may be NULL) */
 int pa2d_gemm_bwd_weight(const float* dy, long long lddy, const float* x, long long ldx, float* dw, float* db,

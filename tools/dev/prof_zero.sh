@@ -1,0 +1,14 @@
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+for z in 0 1; do
+O=gpurun_out/r03_zero_$z; rm -rf $O; mkdir -p $O
+export KBENCH_ZEROS=$z
+timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/stats --output-format csv -- python tools/kbench.py --engine split --only linear_plain,linear_bias_res,conv_fwd,slice_scatter --iters 30 > $O/kb.txt 2>&1
+echo "== zeros=$z"
+python - $O <<'PY'
+import csv, glob, sys
+f = glob.glob(sys.argv[1] + '/stats/*/*kernel_stats.csv')[0]
+for r in list(csv.DictReader(open(f)))[:8]:
+    print(f"{int(r['Calls']):5d} x {float(r['AverageNs'])/1e3:8.1f} us (min {float(r['MinNs'])/1e3:8.1f})  {r['Name'][:100]}")
+PY
+find $O -name "*kernel_trace.csv" -delete; find $O -name "*agent_info.csv" -delete
+done

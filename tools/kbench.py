@@ -44,7 +44,8 @@ def main():
     N, D = H * W, C // heads
     R = B * N
     g = torch.Generator(device=dev).manual_seed(0)
-    rn = lambda *s: torch.randn(*s, device=dev, generator=g)
+    zeros = os.environ.get("KBENCH_ZEROS") == "1"      # all-zero operands: the same instruction stream at low switching power
+    rn = (lambda *s: torch.zeros(*s, device=dev)) if zeros else (lambda *s: torch.randn(*s, device=dev, generator=g))
     xn = rn(B, N, C)
     wx, wf = rn(C, C, 3, 3) * 0.02, rn(C, C, 3, 3) * 0.02
     bx, bf = rn(C), rn(C)

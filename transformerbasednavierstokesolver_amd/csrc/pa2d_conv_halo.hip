@@ -29,10 +29,16 @@ constexpr int HH = TH + 2, HWD = TW + 2, HROWS = HH * HWD;          // 10 x 34 =
 
 // TPB = taps per weight stage (= per barrier): 1 for NT = 3 (96 MFMAs per consumer wave and barrier; LDS is full), 3 for
 // NT = 1 (one tap would be 16 MFMAs per barrier: the kernel would spend its time in s_barrier)
-template <int NT, typename TO = float, int TPB = (NT == 1 ? 3 : 1)>
+// MF16: the consumers issue v_mfma_f32_16x16x32_bf16 (8 x 4 tiles of 16 pixels x 16 channels per wave) instead of
+// v_mfma_f32_32x32x16_bf16 (4 x 2 tiles of 32 x 32): the same fragments, bytes, MACs and matrix-pipe cycles, but the kernel
+// is POWER-limited on real data (1.30 ms on random operands, 0.99 ms on zeros) and the 16x16x32 shape sustains ~1.10x the
+// FLOP/s at the clock the chip holds under that load (tools/probes/mfma_shape_probe.hip: 1905 vs 1730 TFLOP/s).  The weights
+// are the A operand there, so a lane's accumulator quad is four consecutive channels of one pixel: 16-byte stores.
+// Row pitch: an even number (14) of 16-byte slots keeps the 16-row fragment reads conflict-free (13 is the 32-row optimum).
+template <int NT, typename TO = float, int TPB = (NT == 1 ? 3 : 1), bool MF16 = false>
 __global__ __launch_bounds__(512, 1) void conv_halo_kernel(const KCParams p, const int tiles_x, const int tiles_y,
                                                            const int nimg) {
-    constexpr int PITCHB = NT * 64 + 16;
+    constexpr int PITCHB = NT * 64 + (MF16 ? 32 : 16);
     constexpr int PIECES = NT * 4;                                   // 16-byte pieces per row and chunk
     constexpr int A_BYTES = HROWS * PITCHB;
     constexpr int B_TAP = BN * PITCHB;                               // weight tile of one tap
@@ -155,6 +161,88 @@ __global__ __launch_bounds__(512, 1) void conv_halo_kernel(const KCParams p, con
 
     // ---------------------------------------------------------------------- consumers
     const int wm = wave >> 1, wn = wave & 1;
+    if constexpr (MF16) {
+        static_assert(NT == 3 && TPB == 1, "the 16x16x32 consumers are written for the split engine");
+        const int li = lane & 15, kq = lane >> 4;
+        f32x4 acc[8][4];
+#pragma unroll
+        for (int ib = 0; ib < 8; ++ib)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[ib][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // lane l holds row (l & 15), k-group (l >> 4) of a 16-row x 32-k fragment.  Row block ib = (image row i = ib >> 1,
+        // pixel half h = ib & 1) of the wave's 4 x 32 pixels; column block j = 16 output channels.
+        const unsigned a_frag = (unsigned)((((wm * 4 + 1) * HWD) + 1 + li) * PITCHB + kq * 16);
+        const unsigned b_frag = (unsigned)((wn * 64 + li) * PITCHB + kq * 16);
+        __syncthreads();                                      // #0
+        int tap = 0;
+        for (int sg = 0; sg < nst; ++sg) {
+            const int dy = tap / 3 - 1, dx = tap - (tap / 3) * 3 - 1;
+            const unsigned char* af_base = a_s + a_frag + (dy * HWD + dx) * PITCHB;
+            const unsigned char* bf_base = b_s + (sg & 1) * B_STAGE + b_frag;
+            bf16x8 bf[4][NT];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int q = 0; q < NT; ++q) bf[j][q] = *reinterpret_cast<const bf16x8*>(bf_base + j * 16 * PITCHB + q * 64);
+#pragma unroll
+            for (int ib = 0; ib < 8; ++ib) {
+                bf16x8 af[NT];
+#pragma unroll
+                for (int q = 0; q < NT; ++q)
+                    af[q] = *reinterpret_cast<const bf16x8*>(af_base + (ib >> 1) * (HWD * PITCHB) + (ib & 1) * 16 * PITCHB + q * 64);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {                 // smallest terms first; weights = A operand (rows = channels)
+                    acc[ib][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][1], af[1], acc[ib][j], 0, 0, 0);
+                    acc[ib][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][0], af[2], acc[ib][j], 0, 0, 0);
+                    acc[ib][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][2], af[0], acc[ib][j], 0, 0, 0);
+                    acc[ib][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][0], af[1], acc[ib][j], 0, 0, 0);
+                    acc[ib][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][1], af[0], acc[ib][j], 0, 0, 0);
+                    acc[ib][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][0], af[0], acc[ib][j], 0, 0, 0);
+                }
+            }
+            ++tap;
+            __syncthreads();                                  // end of stage sg
+            if (tap == 9) {
+                tap = 0;
+                if (sg + 1 < nst) __syncthreads();            // the producers swapped the halo tile in between
+            }
+        }
+        // epilogue: accumulator quad r = 0..3 of lane l = channels col0 + j*16 + 4*(l>>4) + r of pixel x0 + (ib&1)*16 + (l&15)
+        // of image row y0 + wm*4 + (ib>>1): one 16-byte (fp32) / 8-byte (bf16) store per quad
+        const __amdgpu_buffer_rsrc_t rc = make_rsrc(p.C, p.c_bytes);
+        constexpr unsigned ES = Act<TO>::ES;
+        const unsigned ldc_b = (unsigned)p.ldc * ES, roww_b = (unsigned)p.W * ldc_b;
+        const bool inside = y0 + TH <= p.H && x0 + TW <= p.W;      // wave-uniform
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = tile_n * BN + wn * 64 + j * 16 + 4 * kq;
+            const bool col_ok = col < p.N;                    // N % 4 == 0 (checked by the launcher)
+            float bv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                bv[e] = (p.bias && col_ok) ? (col + e < p.bias_split ? p.bias[col + e] : p.bias2[col + e - p.bias_split]) : 0.f;
+#pragma unroll
+            for (int ib = 0; ib < 8; ++ib) {
+                const int y = y0 + wm * 4 + (ib >> 1), x = x0 + (ib & 1) * 16 + li;
+                const bool ok = col_ok && (inside || (y < p.H && x < p.W));
+                const unsigned off = ok ? (unsigned)((img * p.H + y) * p.W + x) * ldc_b + (unsigned)col * ES : OOB_OFF;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[ib][j][e] + bv[e];
+                if constexpr (ES == 4) {
+                    const u32x4 u = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(u, rc, off, 0, 0);
+                } else {
+                    typedef unsigned int u32x2_ __attribute__((ext_vector_type(2)));
+                    const u32x2_ u = {(unsigned)f32_to_bf16_bits(v[0]) | ((unsigned)f32_to_bf16_bits(v[1]) << 16),
+                                      (unsigned)f32_to_bf16_bits(v[2]) | ((unsigned)f32_to_bf16_bits(v[3]) << 16)};
+                    __builtin_amdgcn_raw_buffer_store_b64(u, rc, off, 0, 0);
+                }
+            }
+        }
+        (void)roww_b;
+        return;
+    }
     f32x16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -274,7 +362,15 @@ int launch_conv_halo(const KCParams& p, hipStream_t st) {
     const int pitch = NT * 64 + 16;
     const int smem = HROWS * pitch + 2 * (NT == 1 ? 3 : 1) * BN * pitch;
     // the LDS attribute is set on every launch: it is per device and the call is cheap
-    if (NT == 3) {
+    if (NT == 3 && pa2d_env().conv_mfma16 && (p.N % 4) == 0) {
+        const int smem16 = (HROWS + 2 * BN) * (3 * 64 + 32);
+        {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<3, float, 1, true>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, smem16);
+            if (e != hipSuccess) return (int)e;
+        }
+        hipLaunchKernelGGL((conv_halo_kernel<3, float, 1, true>), grid, dim3(512), smem16, st, p, tiles_x, tiles_y, nimg);
+    } else if (NT == 3) {
         {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<3>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, smem);

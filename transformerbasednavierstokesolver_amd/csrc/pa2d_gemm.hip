@@ -22,6 +22,8 @@ static Pa2dEnv read_env() {
     v.mcb_splits = num("PA2D_MCB_SPLITS", 0);
     v.lin_dw_split = is("PA2D_LIN_DW_SPLIT", "of") ? 0 : 1;
     v.lin_panel = is("PA2D_LIN_PANEL", "of") ? 0 : 1;
+    v.lin_rowpanel = is("PA2D_LIN_ROWPANEL", "of") ? 0 : 1;
+    v.conv_mfma16 = num("PA2D_CONV_MFMA", 16) == 32 ? 0 : 1;
     v.split_big = num("PA2D_SPLIT_BIG", 1);
     v.slice_map = is("PA2D_SLICE_MAP", "l") ? 0 : 1;
     v.default_engine = is("PA2D_GEMM", "f") ? 0 : (is("PA2D_GEMM", "b") ? 2 : 1);
@@ -83,7 +85,24 @@ static int launch_kc(const KCParams& p_in, bool im2col, hipStream_t st, hipEvent
     if (im2col && (p.epi != 0 || p.res)) return PA2D_ERR_ARG;      // conv kernels carry the bias-only epilogue
     if (ev0 && hipEventRecord(ev0, st) != hipSuccess) return PA2D_ERR_ARG;
     int rc;
-    if (panel_applies(p, im2col)) {
+    if (!im2col && p.wimg && rowpanel_applies(p)) {
+        // row-stationary kernel on the whole 128-row rounds, the per-tile kernels on the (< 128-row) tail
+        rc = launch_pack_weight_image(p.wsrc, p.wsn, p.wsk, p.wimg, p.N, p.K, st);
+        if (rc) return rc;
+        KCParams pp = p;
+        pp.M = p.M - p.M % 128;
+        rc = launch_kc_rowpanel(pp, p.wimg, st);
+        if (!rc && pp.M < p.M) {
+            KCParams pt = p_in;
+            pt.wimg = nullptr;
+            pt.M = p.M - pp.M;
+            pt.A = p.A + (size_t)pp.M * p.lda;
+            pt.C = p.C + (size_t)pp.M * p.ldc;
+            if (p.res) pt.res = p.res + (size_t)pp.M * p.ldres;
+            if (p.aux) pt.aux = p.aux + (size_t)pp.M * p.ldaux;
+            rc = launch_kc(pt, false, st);
+        }
+    } else if (panel_applies(p, im2col)) {
         // persistent row-panel kernel on the whole 256-row blocks, the per-tile kernels on the (< 256-row) tail
         KCParams pp = p;
         pp.M = p.M - p.M % 256;
@@ -160,32 +179,51 @@ int pa2d_default_engine(void) { return pa2d_env().default_engine; }
 
 void pa2d_reload_env(void) { g_env = read_env(); }
 
+// bytes of scratch with which the forward / data-gradient linears of an [N, K] weight take their fastest kernel under
+// `engine` (split engine, K in {128, 256}, N % 64 == 0: the row-stationary kernel's weight plane image); the calls
+// work with less (data gradient: at least K*N floats for the transposed weight) on the other kernels
+size_t pa2d_gemm_fwd_workspace(int N, int K, int engine) { return rowpanel_image_bytes(N, K, engine); }
+size_t pa2d_gemm_bwd_data_workspace(int N, int K, int engine) {
+    return (size_t)N * K * sizeof(float) + rowpanel_image_bytes(K, N, engine);
+}
+
 int pa2d_gemm_bias_act_fwd(const float* x, long long ldx, const float* w, long long ldw, const float* bias,
                            const float* res, long long ldres, float* y, long long ldy, float* pre, long long ldpre,
-                           int M, int N, int K, int act, int engine, hipStream_t st) {
+                           void* ws, size_t ws_bytes, int M, int N, int K, int act, int engine, hipStream_t st) {
     KCParams p = {};
     p.engine = engine;
     p.A = x; p.lda = ldx; p.B = w; p.ldb = ldw; p.C = y; p.ldc = ldy; p.bias = bias; p.res = res; p.ldres = ldres;
     p.aux = pre; p.ldaux = ldpre; p.M = M; p.N = N; p.K = K; p.act = act;
     p.epi = (act != ACT_NONE ? EPI_ACT : 0) | (pre ? EPI_STORE_PRE : 0);
+    const size_t img = rowpanel_image_bytes(N, K, engine);
+    if (ws && img && ws_bytes >= img) { p.wimg = ws; p.wsrc = w; p.wsn = ldw; p.wsk = 1; }
     return launch_kc(p, false, st);
 }
 
 // dx[M,K] = (dy[M,N] . w[N,K]) * act'(pre[M,K])   (pre may be NULL -> plain product)
-// wt_ws: K*N floats of scratch for the transposed weight.
+// ws: at least K*N floats (the transposed weight of the per-tile kernels); pa2d_gemm_bwd_data_workspace(N, K, engine)
+// bytes let the split engine's row-stationary kernel run: [transposed weight | weight plane image].
 int pa2d_gemm_bwd_data(const float* dy, long long lddy, const float* w, long long ldw, const float* pre,
-                       long long ldpre, int act, float* dx, long long lddx, float* wt_ws, int M, int N, int K,
+                       long long ldpre, int act, float* dx, long long lddx, void* ws, size_t ws_bytes, int M, int N, int K,
                        int engine, hipStream_t st) {
     if (ldw != K) return PA2D_ERR_ARG;
     if (N & 3) return PA2D_ERR_ARG;
     if (M <= 0) return PA2D_OK;
-    int rc = launch_repack(w, nullptr, wt_ws, 0, N, K, 0, 0, st);
-    if (rc) return rc;
+    if (ws_bytes < (size_t)N * K * sizeof(float)) return PA2D_ERR_WORKSPACE;
+    float* const wt_ws = (float*)ws;
     KCParams p = {};
     p.engine = engine;
     p.A = dy; p.lda = lddy; p.B = wt_ws; p.ldb = N; p.C = dx; p.ldc = lddx; p.M = M; p.N = K; p.K = N;
     p.aux = const_cast<float*>(pre); p.ldaux = ldpre; p.act = act;
     p.epi = (pre && act != ACT_NONE) ? EPI_MUL_DACT : 0;
+    const size_t img = rowpanel_image_bytes(K, N, engine);
+    if (img && ws_bytes >= (size_t)N * K * sizeof(float) + img) {
+        p.wimg = (char*)ws + (size_t)N * K * sizeof(float); p.wsrc = w; p.wsn = 1; p.wsk = ldw;
+    }
+    if (!(p.wimg && rowpanel_applies(p) && (M % 128) == 0)) {      // someone reads the fp32 transpose
+        const int rc = launch_repack(w, nullptr, wt_ws, 0, N, K, 0, 0, st);
+        if (rc) return rc;
+    }
     return launch_kc(p, false, st);
 }
 

@@ -25,6 +25,8 @@ struct KCParams {
     unsigned c_bytes, res_bytes, aux_bytes;
     int apre;   // split engine: A already holds the NT bf16 planes of every 32-channel chunk (split_planes_kernel)
     int engine; // PA2D_ENGINE_* of this call (explicit per call: the library keeps no engine state)
+    void* wimg;  // scratch for the weight plane image of the row-stationary linear kernel (rowpanel_image_bytes), or NULL
+    const float* wsrc; long long wsn, wsk;   // the image's source: B[n][k] = wsrc[n * wsn + k * wsk]
     int io_bf16; // bf16-storage entry points: A (row-major [M][K] or the NHWC image), C, res and aux hold bf16; lda / ldc /
                  // ldres / ldaux stay in ELEMENTS; a bf16 A is read as pre-made 1-plane "planes" (apre = 1)
 };
@@ -149,6 +151,11 @@ int launch_repack_split(const float* w0, const float* w1, void* dst, int bwd, in
 // persistent row-panel kernel for large-M plain GEMMs of the bf16 engines (pa2d_gemm_panel.hip)
 bool panel_applies(const KCParams& p, bool im2col);
 int launch_kc_panel(const KCParams& p, hipStream_t st);
+// row-stationary split-engine linears (pa2d_gemm_rowpanel.hip): need a weight plane image in caller scratch
+size_t rowpanel_image_bytes(int N, int K, int engine);
+bool rowpanel_applies(const KCParams& p);
+int launch_pack_weight_image(const float* w, long long sn, long long sk, void* img, int N, int K, hipStream_t st);
+int launch_kc_rowpanel(const KCParams& p, const void* img, hipStream_t st);
 // conv with the halo tile resident in LDS (pa2d_conv_halo.hip): used by launch_kc_split for pre-split im2col operands
 bool conv_halo_applies(const KCParams& p);
 int launch_conv_halo(const KCParams& p, hipStream_t st);

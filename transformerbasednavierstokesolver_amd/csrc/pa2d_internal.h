@@ -127,6 +127,8 @@ struct Pa2dEnv {
     int mcb_splits;       // PA2D_MCB_SPLITS=n (0 = automatic)
     int lin_dw_split;     // PA2D_LIN_DW_SPLIT=off -> 0
     int lin_panel;        // PA2D_LIN_PANEL=off -> 0
+    int conv_mfma16;      // PA2D_CONV_MFMA=32 -> 0 (halo conv consumers back on v_mfma_f32_32x32x16_bf16)
+    int lin_rowpanel;     // PA2D_LIN_ROWPANEL=off -> 0 (row-stationary linears back on the panel / per-tile kernels)
     int split_big;        // PA2D_SPLIT_BIG=0 -> 0
     int slice_map;        // PA2D_SLICE_MAP=legacy -> 0
     int default_engine;   // PA2D_GEMM=f32|split|bf16 : what pa2d_default_engine() returns

@@ -164,8 +164,11 @@ def linear_fwd(x2d, w, bias=None, res=None, act=None, want_pre=False, engine=Non
         _lib.check(_L().pa2d_gemm_bias_act_fwd_bf16(_p(x2d), K, _p(w), w.shape[1], _p(bias), _p(res), N, _p(y), N,
                                                     _p(pre), N, M, N, K, ACT_IDS[act], _stream()), "gemm_bias_act_fwd_bf16")
     else:
+        eng = _abi_engine(engine)
+        nb = _L().pa2d_gemm_fwd_workspace(N, K, eng)
+        ws = _ws(nb, x2d) if nb else None
         _lib.check(_L().pa2d_gemm_bias_act_fwd(_p(x2d), K, _p(w), w.shape[1], _p(bias), _p(res), N, _p(y), N, _p(pre), N,
-                                               M, N, K, ACT_IDS[act], _abi_engine(engine), _stream()),
+                                               _p(ws), nb, M, N, K, ACT_IDS[act], eng, _stream()),
                    "gemm_bias_act_fwd")
     return y, pre
 
@@ -177,13 +180,16 @@ def linear_bwd_data(dy, w, pre=None, act=None, engine=None):
     M, N = dy.shape
     K = w.shape[1]
     dx = torch.empty(M, K, dtype=dy.dtype, device=dy.device)
-    wt = torch.empty(K * N, dtype=torch.float32, device=dy.device)
     if bf:
+        wt = torch.empty(K * N, dtype=torch.float32, device=dy.device)
         _lib.check(_L().pa2d_gemm_bwd_data_bf16(_p(dy), N, _p(w), K, _p(pre), K, ACT_IDS[act], _p(dx), K, _p(wt), M, N, K,
                                                 _stream()), "gemm_bwd_data_bf16")
     else:
-        _lib.check(_L().pa2d_gemm_bwd_data(_p(dy), N, _p(w), K, _p(pre), K, ACT_IDS[act], _p(dx), K, _p(wt), M, N, K,
-                                           _abi_engine(engine), _stream()), "gemm_bwd_data")
+        eng = _abi_engine(engine)
+        nb = _L().pa2d_gemm_bwd_data_workspace(N, K, eng)
+        ws = _ws(nb, dy)
+        _lib.check(_L().pa2d_gemm_bwd_data(_p(dy), N, _p(w), K, _p(pre), K, ACT_IDS[act], _p(dx), K, ws.data_ptr(), nb, M, N, K,
+                                           eng, _stream()), "gemm_bwd_data")
     return dx
 
 
