@@ -58,6 +58,48 @@ def test_linear_row_panel(dev, M, N, K, act):
     _check_linear(dev, M, N, K, act, "split", FWD_TOL, BWD_TOL)
 
 
+# Row-stationary kernel of the split engine (K in {128, 256}, N % 128 == 0, >= 256 rounds of 128 rows, scratch from
+# pa2d_gemm_fwd_workspace / pa2d_gemm_bwd_data_workspace): every epilogue (plain, bias, bias + residual, GELU with and
+# without the saved pre-activation, GELU' data gradient), both K, 2 / 4 / 8 column pairs, one and several rounds per
+# workgroup, a ragged tail of < 128 rows; and the same calls with the kernel switched off agree to fp32 rounding.
+@pytest.mark.parametrize("M,N,K", [(32768, 128, 128), (33285, 256, 128), (40000, 128, 256), (65536 + 128 * 5 + 77, 256, 256),
+                                   (33000, 512, 256)])
+def test_linear_row_stationary(dev, kernel_env, M, N, K):
+    from transformerbasednavierstokesolver_amd import ops, _lib
+    from oracle import transolver_oracle as orc
+    assert _lib.load().pa2d_gemm_fwd_workspace(N, K, 1) == N * K * 6
+    rng = np.random.default_rng(M + N + K)
+    x, w, b, res = _r(rng, M, K), _r(rng, N, K, scale=K ** -0.5), 0.1 * _r(rng, N), _r(rng, M, N)
+    dy, pre2 = _r(rng, M, N), _r(rng, M, K)
+    xd, wd, bd = x.to(dev).double(), w.to(dev).double(), b.to(dev).double()
+    lin = xd @ wd.t()
+    p2 = pre2.to(dev).double().requires_grad_(True)
+    orc._ACTS["gelu"](p2).backward(torch.ones(M, K, dtype=torch.float64, device=dev))
+    want = {"plain": lin, "bias": lin + bd, "bias_res": lin + bd + res.to(dev).double(),
+            "gelu": orc._ACTS["gelu"](lin + bd), "pre": lin + bd,
+            "bwd": dy.to(dev).double() @ wd, "bwd_gelu": (dy.to(dev).double() @ wd) * p2.grad}
+
+    def run():
+        X, W, Bv, R, DY, P2 = (t.to(dev) for t in (x, w, b, res, dy, pre2))
+        out = {"plain": ops.linear_fwd(X, W, engine="split")[0], "bias": ops.linear_fwd(X, W, Bv, engine="split")[0],
+               "bias_res": ops.linear_fwd(X, W, Bv, res=R, engine="split")[0]}
+        out["gelu"], out["pre"] = ops.linear_fwd(X, W, Bv, act="gelu", want_pre=True, engine="split")
+        out["gelu_nopre"] = ops.linear_fwd(X, W, Bv, act="gelu", engine="split")[0]
+        out["bwd"] = ops.linear_bwd_data(DY, W, engine="split")      # dx[M, K] = dy[M, N] . w[N, K]
+        out["bwd_gelu"] = ops.linear_bwd_data(DY, W, pre=P2, act="gelu", engine="split")
+        return out
+
+    got = run()
+    for k in ("plain", "bias", "bias_res", "gelu", "pre"):
+        assert rel_l2(got[k], want[k]) < FWD_TOL, k
+    assert torch.equal(got["gelu_nopre"], got["gelu"])
+    assert rel_l2(got["bwd"], want["bwd"]) < BWD_TOL and rel_l2(got["bwd_gelu"], want["bwd_gelu"]) < BWD_TOL
+    kernel_env(PA2D_LIN_ROWPANEL="off")
+    ref = run()
+    for k in got:
+        assert rel_l2(got[k], ref[k]) < 1e-6, k
+
+
 def _check_linear(dev, M, N, K, act, engine, FWD_TOL, BWD_TOL):
     from transformerbasednavierstokesolver_amd import ops
     from oracle import transolver_oracle as orc
