@@ -3,14 +3,16 @@
 // gemm_panel_kernel (pa2d_gemm_panel.hip) splits every A element once per 128-column tile in dedicated producer waves
 // whose VALU work, and whose consumers' store-only epilogue, add to the MFMA time instead of hiding behind it
 // (measured there: 0.056 ms of MFMAs inside a 0.116 ms launch).  Here the ACTIVATION rows are the stationary operand:
-//   * a wave owns 32 rows for a whole round: it loads them once (fragment-shaped: lane (row l&31, k-half l>>5) reads
-//     the 8 consecutive k of its MFMA A fragment), splits them once into the three bf16 planes (x = hi + mid + lo) and
-//     keeps all K/16 fragments x 3 planes in registers (192 VGPRs at K = 256; one wave per SIMD);
+//   * a wave owns 32 rows (two 16-row blocks) for a whole round: it loads them once (fragment-shaped: lane (row l&15,
+//     k-group l>>4) reads the 8 consecutive k of its MFMA fragment), splits them once into the three bf16 planes
+//     (x = hi + mid + lo) and keeps all K/32 x 2 fragments x 3 planes in registers (192 VGPRs at K = 256; one wave per SIMD);
 //   * the WEIGHTS come as a fragment-ordered plane image made once per launch by pack_weight_image_kernel (N*K*6 bytes,
 //     L2-resident, read by every workgroup): 24 KB stages (64 columns x 64 k x 3 planes) go global -> registers -> LDS
 //     one stage ahead and are read back conflict-free with ds_read_b128 (the image IS the lane order);
-//   * the four waves of a workgroup (128 rows) share each stage; per stage a wave issues 48 MFMAs 32x32x16 (6 terms of
-//     order <= 2 per fragment pair, smallest first, fp32 accumulate);
+//   * the four waves of a workgroup (128 rows) share each stage; per stage a wave issues 96 MFMAs 16x16x32 (6 terms of
+//     order <= 2 per fragment pair, smallest first, fp32 accumulate).  16x16x32, not 32x32x16: the same fragments, bytes
+//     and matrix-pipe cycles, but these kernels are power-limited on real data and the narrower shape holds ~1.10x the
+//     FLOP/s at the clock the chip sustains (tools/probes/mfma_shape_probe.hip);
 //   * a 64-column pair of accumulators is finished every K/64 stages and stored straight away, so the C writes, the
 //     residual / pre-activation reads (fetched one pair ahead) and the next round's A rows (fetched during the first
 //     stages of this round) are spread evenly over the launch instead of arriving in bursts.
@@ -39,23 +41,25 @@ __device__ __forceinline__ void st4s(__amdgpu_buffer_rsrc_t r, unsigned voff, un
 }
 __device__ __forceinline__ bf16x8 cat8(bf16x4 a, bf16x4 b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
 
-// image[stage = np * KC + kc][ks4][nt2][plane][lane] (16 B) = plane of B[64 np + 32 nt2 + (lane & 31)][64 kc + 16 ks4 + 8 (lane >> 5) + 0..7]
+// image[stage = np * KC + kc][s = 0..3][j = 0..1][plane][lane] (16 B): sub-step s = (32-k step s >> 1, column half s & 1),
+// column tile nt = 2 (s & 1) + j of 16 columns; lane (li = l & 15, kq = l >> 4) holds the plane of
+// B[64 np + 16 nt + li][64 kc + 32 (s >> 1) + 8 kq + 0..7]
 // B[n][k] = src[n * sn + k * sk] (sk = 1: the weight as stored, forward; sn = 1: its transpose, data gradient)
 __global__ void pack_weight_image_kernel(const float* __restrict__ src, long long sn, long long sk, unsigned char* __restrict__ img,
                                          int N, int K) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // one fragment lane: (stage, ks4, nt2, lane)
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // one fragment lane: (stage, s, j, lane)
     const int KC = K / 64;
     if (idx >= (N / 64) * KC * 8 * 64) return;
-    const int lane = idx & 63, nt2 = (idx >> 6) & 1, ks4 = (idx >> 7) & 3, stage = idx >> 9;
+    const int lane = idx & 63, j = (idx >> 6) & 1, sub = (idx >> 7) & 3, stage = idx >> 9;
     const int np = stage / KC, kc = stage % KC;
-    const int n = 64 * np + 32 * nt2 + (lane & 31), k0 = 64 * kc + 16 * ks4 + 8 * (lane >> 5);
+    const int n = 64 * np + 16 * (2 * (sub & 1) + j) + (lane & 15), k0 = 64 * kc + 32 * (sub >> 1) + 8 * (lane >> 4);
     float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = src[(long long)n * sn + (long long)(k0 + j) * sk];
+    for (int e = 0; e < 8; ++e) v[e] = src[(long long)n * sn + (long long)(k0 + e) * sk];
     bf16x4 h0, m0, l0, h1, m1, l1;
     split3(make_float4(v[0], v[1], v[2], v[3]), h0, m0, l0);
     split3(make_float4(v[4], v[5], v[6], v[7]), h1, m1, l1);
-    unsigned char* dst = img + (size_t)stage * RP_STAGE + (size_t)((ks4 * 2 + nt2) * 3) * 1024 + lane * 16;
+    unsigned char* dst = img + (size_t)stage * RP_STAGE + (size_t)((sub * 2 + j) * 3) * 1024 + lane * 16;
     *reinterpret_cast<bf16x8*>(dst) = cat8(h0, h1);
     *reinterpret_cast<bf16x8*>(dst + 1024) = cat8(m0, m1);
     *reinterpret_cast<bf16x8*>(dst + 2048) = cat8(l0, l1);
@@ -70,7 +74,7 @@ __global__ __launch_bounds__(256, 1) void gemm_rowpanel_kernel(const KCParams p,
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int li = lane & 31, kq = lane >> 5;
+    const int li = lane & 15, kq = lane >> 4;
     const int NP = p.N / 64, SPR = NP * KC;                  // stages per round
     float* const bias_s = reinterpret_cast<float*>(smem);      // [N <= 1024] (zeros without a bias); the stage ring follows
     unsigned char* const ring = smem + RP_BIAS;
@@ -104,13 +108,15 @@ __global__ __launch_bounds__(256, 1) void gemm_rowpanel_kernel(const KCParams p,
         for (int i = 0; i < 6; ++i) *reinterpret_cast<u32x4_*>(ring + slot * RP_STAGE + piece + i * 1024) = breg[i];
     };
 
-    // ---- activation rows: raw fragment-shaped loads (two float4 per k-step) and their split
+    // ---- activation rows: raw fragment-shaped loads (two float4 per unit) and their split.  Unit u = (32-k step u >> 1,
+    // 16-row block u & 1): K/16 units per round, four per 64-k chunk
     const unsigned a_voff = (unsigned)li * lda_b + (unsigned)kq * 32u;
     float4 raw[KS][2];
     bf16x8 ap[KS][3];
-    auto a_load = [&](int ks, unsigned voff, unsigned row0) {      // voff == OOB_OFF: reads nothing (zeros)
-        raw[ks][0] = ld4s(ra, voff == OOB_OFF ? OOB_OFF : voff + ks * 64u, row0 * lda_b);
-        raw[ks][1] = ld4s(ra, voff == OOB_OFF ? OOB_OFF : voff + ks * 64u + 16u, row0 * lda_b);
+    auto a_load = [&](int u, unsigned voff, unsigned row0) {       // voff == OOB_OFF: reads nothing (zeros)
+        const unsigned so = (row0 + 16u * (u & 1)) * lda_b;
+        raw[u][0] = ld4s(ra, voff == OOB_OFF ? OOB_OFF : voff + (u >> 1) * 128u, so);
+        raw[u][1] = ld4s(ra, voff == OOB_OFF ? OOB_OFF : voff + (u >> 1) * 128u + 16u, so);
     };
     auto a_split = [&](int ks) {
         bf16x4 h0, m0, l0, h1, m1, l1;
@@ -130,14 +136,13 @@ __global__ __launch_bounds__(256, 1) void gemm_rowpanel_kernel(const KCParams p,
     for (int ks = 0; ks < KS; ++ks) a_split(ks);
     __syncthreads();
 
-    // The weights are the MFMA's A operand and the activation rows its B operand, so a lane's accumulator holds ONE output
-    // row (row0 + li) and, per group of four registers, four CONSECUTIVE columns 8 q + 4 kq + 0..3 of the 32-column tile:
-    // the epilogue moves 16 bytes per lane and instruction.  Per-lane byte offsets of (row li, column 4 kq); rows of the
-    // round and column groups add SGPR offsets.
+    // The weights are the MFMA's A operand and the activation rows its B operand, so a lane's accumulator quad holds ONE
+    // output row (row0 + 16 rb + li) and four CONSECUTIVE columns 4 kq + 0..3 of a 16-column tile: the epilogue moves 16
+    // bytes per lane and instruction.  Per-lane byte offsets of (row li, column 4 kq); row blocks and tiles add SGPR offsets.
     const unsigned vc = li * ldc_b + kq * 16u, vr = li * ldres_b + kq * 16u, vx = li * ldaux_b + kq * 16u;
 
-    // B fragments of one k-step (2 column tiles x 3 planes), double-buffered: the reads of k-step q + 1 are issued before
-    // the MFMAs of k-step q
+    // B fragments of one sub-step (2 column tiles x 3 planes), double-buffered: the reads of sub-step s + 1 are issued
+    // before the MFMAs of sub-step s
     bf16x8 bfb[2][2][3];
     int cur = 0;                                             // LDS slot of the current stage (ring of 3)
     auto frag_read = [&](int buf, int slot, int ks4) {
@@ -149,33 +154,34 @@ __global__ __launch_bounds__(256, 1) void gemm_rowpanel_kernel(const KCParams p,
     };
     frag_read(0, 0, 0);
 
-    f32x16 acc[2];
+    f32x4 acc[2][4];                                         // [row block][16-column tile of the pair]
     float4 ov[2][4];                                         // residual / pre-activation operands, fetched at the pair's start
-    auto ep_group = [&](const int q8, const int np) {        // 4 columns x 32 rows: one register quad per lane
-        const int j = q8 >> 2, q = q8 & 3;
-        const unsigned cb = (unsigned)(np * 64 + j * 32 + q * 8) * 4u;
+    auto ep_group = [&](const int q8, const int np) {        // 16 rows x 16 columns: one register quad per lane
+        const int rb = q8 >> 2, nt = q8 & 3;
+        const unsigned cb = (unsigned)(np * 64 + nt * 16) * 4u;
+        const unsigned rw = row0 + 16u * rb;
         float v[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = acc[j][4 * q + e];
+        for (int e = 0; e < 4; ++e) v[e] = acc[rb][nt][e];
         if (MODE == 1) {
-            st4s(raux, vx, row0 * ldaux_b + cb, v);
+            st4s(raux, vx, rw * ldaux_b + cb, v);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
         } else if (MODE == 2) {
-            v[0] *= dgelu_f(ov[j][q].x); v[1] *= dgelu_f(ov[j][q].y); v[2] *= dgelu_f(ov[j][q].z); v[3] *= dgelu_f(ov[j][q].w);
+            v[0] *= dgelu_f(ov[rb][nt].x); v[1] *= dgelu_f(ov[rb][nt].y); v[2] *= dgelu_f(ov[rb][nt].z); v[3] *= dgelu_f(ov[rb][nt].w);
         } else if (HAS_RES) {
-            v[0] += ov[j][q].x; v[1] += ov[j][q].y; v[2] += ov[j][q].z; v[3] += ov[j][q].w;
+            v[0] += ov[rb][nt].x; v[1] += ov[rb][nt].y; v[2] += ov[rb][nt].z; v[3] += ov[rb][nt].w;
         }
 #ifdef RP_NO_STORE
         if (p.M == 12345)
 #endif
-        st4s(rc, vc, row0 * ldc_b + cb, v);
+        st4s(rc, vc, rw * ldc_b + cb, v);
     };
     auto ov_load = [&](const int q8, const int np) {         // operands of group q8 of the CURRENT pair
-        const int j = q8 >> 2, q = q8 & 3;
-        const unsigned cb = (unsigned)(np * 64 + j * 32 + q * 8) * 4u;
-        if (MODE == 2) ov[j][q] = ld4s(raux, vx, row0 * ldaux_b + cb);
-        else if (HAS_RES) ov[j][q] = ld4s(rres, vr, row0 * ldres_b + cb);
+        const int rb = q8 >> 2, nt = q8 & 3;
+        const unsigned cb = (unsigned)(np * 64 + nt * 16) * 4u;
+        if (MODE == 2) ov[rb][nt] = ld4s(raux, vx, (row0 + 16u * rb) * ldaux_b + cb);
+        else if (HAS_RES) ov[rb][nt] = ld4s(rres, vr, (row0 + 16u * rb) * ldres_b + cb);
     };
 
     unsigned row0n = 0, a_voff_n = OOB_OFF;
@@ -184,13 +190,14 @@ __global__ __launch_bounds__(256, 1) void gemm_rowpanel_kernel(const KCParams p,
     auto pair = [&](auto first_tag, auto last_tag, const int np) {
         constexpr bool FIRST = decltype(first_tag)::value, LAST = decltype(last_tag)::value;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int nt = 0; nt < 4; ++nt) {
+            const float4 bv = *reinterpret_cast<const float4*>(bias_s + np * 64 + nt * 16 + 4 * kq);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float4 bv = *reinterpret_cast<const float4*>(bias_s + np * 64 + j * 32 + q * 8 + 4 * kq);
-                acc[j][4 * q + 0] = bv.x; acc[j][4 * q + 1] = bv.y; acc[j][4 * q + 2] = bv.z; acc[j][4 * q + 3] = bv.w;
-                ov_load(j * 4 + q, np);
+            for (int rb = 0; rb < 2; ++rb) {
+                acc[rb][nt] = f32x4{bv.x, bv.y, bv.z, bv.w};
+                ov_load(rb * 4 + nt, np);
             }
+        }
 #pragma unroll
         for (int kc = 0; kc < KC; ++kc) {
             // Stage g sits in slot cur.  Stage g + 1 is in registers and goes to slot nxt now: its last readers (stage g - 2)
@@ -218,9 +225,11 @@ __global__ __launch_bounds__(256, 1) void gemm_rowpanel_kernel(const KCParams p,
                 if (LAST && kc >= 1) a_split(ks - 4);
                 if (FIRST && kc == 0) a_split(KS - 4 + ks4);
 #endif
+                // sub-step ks4: 32-k step ks4 >> 1 of the chunk, column tiles 2 (ks4 & 1) + j; units (k-step, row block rb)
 #define RP_MFMA(u_, v_)                                                                                      \
-    _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                             \
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bfb[ks4 & 1][j][v_], ap[ks][u_], acc[j], 0, 0, 0);
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) _Pragma("unroll") for (int rb = 0; rb < 2; ++rb)            \
+        acc[rb][2 * (ks4 & 1) + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(                                 \
+            bfb[ks4 & 1][j][v_], ap[kc * 4 + (ks4 >> 1) * 2 + rb][u_], acc[rb][2 * (ks4 & 1) + j], 0, 0, 0);
 #ifndef RP_NO_MFMA
                 RP_MFMA(1, 1) RP_MFMA(2, 0) RP_MFMA(0, 2) RP_MFMA(1, 0) RP_MFMA(0, 1) RP_MFMA(0, 0)
 #endif
@@ -228,7 +237,7 @@ __global__ __launch_bounds__(256, 1) void gemm_rowpanel_kernel(const KCParams p,
 #if RP_SGB == 1
 #pragma unroll
                 for (int i = 0; i < 6; ++i) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
                     __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 }
 #endif
