@@ -49,9 +49,9 @@ PEAK_HBM_GBS = 8000.0             # HBM3E, MI355X_MICROARCH.md
 # dominant (conv implicit-GEMM) kernel and the MFMA peak it is priced against, per engine.  Split engine: six bf16
 # MFMA terms per fp32 product -> fp32-equivalent peak = dense bf16 peak / 6.
 CONV_KERNELS = {ops.ENGINE_F32: ("gemm_kc_kernel<128,128,2,2,true,32>", PEAK_FP32_MFMA_TFLOPS),
-                ops.ENGINE_SPLIT: ("conv_halo_kernel<3>", round(PEAK_BF16_MFMA_TFLOPS / 6, 1)),
-                ops.ENGINE_BF16: ("conv_halo_kernel<1>", PEAK_BF16_MFMA_TFLOPS),
-                ops.ENGINE_BF16S: ("conv_halo_kernel<1,bf16>", PEAK_BF16_MFMA_TFLOPS)}
+                ops.ENGINE_SPLIT: ("conv_halo_kernel<3, float, 1, true>", round(PEAK_BF16_MFMA_TFLOPS / 6, 1)),   # 16x16x32 MFMA consumers
+                ops.ENGINE_BF16: ("conv_halo_kernel<1, float, 3, false>", PEAK_BF16_MFMA_TFLOPS),
+                ops.ENGINE_BF16S: ("conv_halo_kernel<1, __bf16, 3, false>", PEAK_BF16_MFMA_TFLOPS)}
 ENGINE_LABEL = {ops.ENGINE_F32: "exact fp32 MFMA (all GEMMs)",
                 ops.ENGINE_SPLIT: "3xbf16-split/fp32-acc (conv and large-M linear GEMMs, forward / data / weight "
                                   "gradients); exact fp32 MFMA for the small GEMMs",
