@@ -77,17 +77,24 @@ int pa2d_layernorm_bwd(const float* dy, const float* x, const float* mean, const
  * the weight as a bf16 plane image made in ws by this call; results do not depend on which kernel ran beyond fp32
  * summation order. */
 size_t pa2d_gemm_fwd_workspace(int N, int K, int engine);
+/* The image on its own, for callers that know the weights stand still over several calls (the model calls and the
+ * backward pass of one training iteration; a rollout): made once, passed as `wimg` (then ws may be NULL).
+ * transposed = 0: image of w[N, K] for the layer's forward; 1: image of w^T for its data gradient (N = the layer's input
+ * width, K = its output width, w stored [K, N]).  PA2D_ERR_UNSUPPORTED where pa2d_gemm_fwd_workspace(N, K, engine) is 0. */
+int pa2d_gemm_weight_image(const float* w, long long ldw, int transposed, void* img, size_t img_bytes, int N, int K,
+                           int engine, pa2d_stream_t stream);
 int pa2d_gemm_bias_act_fwd(const float* x, long long ldx, const float* w, long long ldw, const float* bias,
                            const float* res, long long ldres, float* y, long long ldy, float* pre,
-                           long long ldpre, void* ws, size_t ws_bytes, int M, int N, int K, int act, int engine,
-                           pa2d_stream_t stream);
+                           long long ldpre, const void* wimg, void* ws, size_t ws_bytes, int M, int N, int K, int act,
+                           int engine, pa2d_stream_t stream);
 /* dx[M,K] = (dy[M,N] . w[N,K]) * act'(pre[M,K])  (pre NULL -> no activation factor);
  * ws: at least K*N floats (transposed weight; PA2D_ERR_WORKSPACE below that); pa2d_gemm_bwd_data_workspace(N, K,
- * engine) bytes also hold the weight plane image of the row-stationary kernel (as for the forward). */
+ * engine) bytes also hold the weight plane image of the row-stationary kernel (as for the forward); wimg (may be NULL):
+ * a ready-made image of w^T, pa2d_gemm_weight_image(w, K, 1, img, bytes, K, N, engine). */
 size_t pa2d_gemm_bwd_data_workspace(int N, int K, int engine);
 int pa2d_gemm_bwd_data(const float* dy, long long lddy, const float* w, long long ldw, const float* pre,
-                       long long ldpre, int act, float* dx, long long lddx, void* ws, size_t ws_bytes, int M, int N,
-                       int K, int engine, pa2d_stream_t stream);
+                       long long ldpre, int act, float* dx, long long lddx, const void* wimg, void* ws, size_t ws_bytes,
+                       int M, int N, int K, int engine, pa2d_stream_t stream);
 size_t pa2d_gemm_bwd_weight_workspace(int M, int N, int K, int engine);
 /* dw[N,K] (+)= dy[M,N]^T . x[M,K];  db[N] (+)= column sums of dy (db may be NULL) */
 int pa2d_gemm_bwd_weight(const float* dy, long long lddy, const float* x, long long ldx, float* dw, float* db,

@@ -415,9 +415,9 @@ def test_c_abi_error_codes_on_device():
     ptr = t.data_ptr()
     st = torch.cuda.current_stream().cuda_stream
     # K not a multiple of 4 -> ARG
-    assert L.pa2d_gemm_bias_act_fwd(ptr, 6, ptr, 6, 0, 0, 8, ptr, 8, 0, 8, 0, 0, 16, 8, 6, 0, 0, st) == 1001
+    assert L.pa2d_gemm_bias_act_fwd(ptr, 6, ptr, 6, 0, 0, 8, ptr, 8, 0, 8, 0, 0, 0, 16, 8, 6, 0, 0, st) == 1001
     # unknown engine id -> ARG
-    assert L.pa2d_gemm_bias_act_fwd(ptr, 8, ptr, 8, 0, 0, 8, ptr, 8, 0, 8, 0, 0, 16, 8, 8, 0, 7, st) == 1001
+    assert L.pa2d_gemm_bias_act_fwd(ptr, 8, ptr, 8, 0, 0, 8, ptr, 8, 0, 8, 0, 0, 0, 16, 8, 8, 0, 7, st) == 1001
     # LayerNorm width not a multiple of 4 -> UNSUPPORTED
     assert L.pa2d_layernorm_fwd(ptr, ptr, ptr, ptr, ptr, ptr, 4, 30, 1e-5, st) == 1002
     # more slices than the token kernel holds -> UNSUPPORTED
@@ -433,7 +433,7 @@ def test_c_abi_error_codes_on_device():
     for engine in (0, 1, 2):
         assert L.pa2d_conv3x3x2_fwd(ptr, ptr, ptr, ptr, ptr, ptr, 0, ptr, 16, 1, 4, 4, 16, engine, st, 0, 0) == 1003
     # a problem whose operand would exceed the 4 GiB buffer-descriptor extent -> UNSUPPORTED (nothing launched)
-    assert L.pa2d_gemm_bias_act_fwd(ptr, 512, ptr, 512, 0, 0, 512, ptr, 512, 0, 512, 0, 0, 2200000, 512, 512, 0, 0, st) == 1002
+    assert L.pa2d_gemm_bias_act_fwd(ptr, 512, ptr, 512, 0, 0, 512, ptr, 512, 0, 512, 0, 0, 0, 2200000, 512, 512, 0, 0, st) == 1002
     torch.cuda.synchronize()
     with pytest.raises(RuntimeError, match="PA2D_ERR"):
         _lib.check(1002, "probe")

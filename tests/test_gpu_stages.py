@@ -79,8 +79,9 @@ def test_linear_row_stationary(dev, kernel_env, M, N, K):
             "gelu": orc._ACTS["gelu"](lin + bd), "pre": lin + bd,
             "bwd": dy.to(dev).double() @ wd, "bwd_gelu": (dy.to(dev).double() @ wd) * p2.grad}
 
+    X, W, Bv, R, DY, P2 = (t.to(dev) for t in (x, w, b, res, dy, pre2))
+
     def run():
-        X, W, Bv, R, DY, P2 = (t.to(dev) for t in (x, w, b, res, dy, pre2))
         out = {"plain": ops.linear_fwd(X, W, engine="split")[0], "bias": ops.linear_fwd(X, W, Bv, engine="split")[0],
                "bias_res": ops.linear_fwd(X, W, Bv, res=R, engine="split")[0]}
         out["gelu"], out["pre"] = ops.linear_fwd(X, W, Bv, act="gelu", want_pre=True, engine="split")
@@ -94,6 +95,12 @@ def test_linear_row_stationary(dev, kernel_env, M, N, K):
         assert rel_l2(got[k], want[k]) < FWD_TOL, k
     assert torch.equal(got["gelu_nopre"], got["gelu"])
     assert rel_l2(got["bwd"], want["bwd"]) < BWD_TOL and rel_l2(got["bwd_gelu"], want["bwd_gelu"]) < BWD_TOL
+    with ops.weights_frozen() as scope:      # images made once per weight (pa2d_gemm_weight_image) and passed ready-made
+        frozen = run()
+        frozen2 = run()
+        assert len(scope.images) == (2 if K <= 256 and N <= 256 else 1)      # forward image, transposed image
+    for k in got:
+        assert torch.equal(frozen[k], got[k]) and torch.equal(frozen2[k], got[k]), k
     kernel_env(PA2D_LIN_ROWPANEL="off")
     ref = run()
     for k in got:
@@ -274,6 +281,22 @@ def test_conv_split_engine_both_kernels(dev, kernel_env, B, H, W, C, policy):
     tiles and column groups whose taps change inside a tile) vs the 128x128 one (PA2D_MC_BIG=off)."""
     kernel_env(PA2D_CONV_HALO=policy, PA2D_MC_BIG="off" if policy == "off" else None)
     _check_conv(dev, B, H, W, C, "split", FWD_TOL, BWD_TOL)
+
+
+@pytest.mark.parametrize("B,H,W,C", [(2, 64, 64, 256), (1, 21, 17, 128), (1, 45, 70, 64)])
+def test_conv_halo_both_mfma_shapes(dev, kernel_env, B, H, W, C):
+    """The halo conv's consumers exist on v_mfma_f32_16x16x32_bf16 (default: faster on real data) and on 32x32x16
+    (PA2D_CONV_MFMA=32): both meet the fp32 tolerances, also on ragged tiles, and agree to fp32 rounding."""
+    from transformerbasednavierstokesolver_amd import ops
+    rng = np.random.default_rng(B + H + C)
+    xn, wx, wf = _r(rng, B, H * W, C).to(dev), (_r(rng, C, C, 3, 3) * 0.05).to(dev), (_r(rng, C, C, 3, 3) * 0.05).to(dev)
+    bx, bf = _r(rng, C).to(dev), _r(rng, C).to(dev)
+    outs = {}
+    for shape in ("16", "32"):
+        kernel_env(PA2D_CONV_HALO="force", PA2D_CONV_MFMA=shape)
+        _check_conv(dev, B, H, W, C, "split", FWD_TOL, BWD_TOL)
+        outs[shape] = ops.conv3x3x2_fwd(xn, wx, bx, wf, bf, H, W, engine="split")
+    assert rel_l2(outs["16"], outs["32"]) < 1e-6
 
 
 def test_bf16_compute_engine_stage_tolerances(dev, kernel_env):

@@ -177,3 +177,20 @@ def test_size_helpers_accept_empty_problems():
     assert lib.pa2d_slice_bwd_workspace(0, 4096, 8, 8, 32) >= 0 and lib.pa2d_sumsq_workspace(0) >= 0
     assert lib.pa2d_slice_nchunk(0, 4096, 8) >= 1 and lib.pa2d_slice_nchunk(1, 0, 8) == 1
     assert lib.pa2d_token_attn_bwd_workspace(0, 8) >= 0
+
+
+def test_linear_scratch_queries():
+    """pa2d_gemm_fwd_workspace / pa2d_gemm_bwd_data_workspace: the weight plane image of the row-stationary kernel
+    (N*K*6 bytes) for the split engine's K in {128, 256}, N % 128 == 0 layers, nothing for other shapes / engines; the
+    data gradient always wants the K*N-float transpose in front of it."""
+    from transformerbasednavierstokesolver_amd import _lib
+    lib = _lib.load()
+    assert lib.pa2d_gemm_fwd_workspace(256, 256, 1) == 256 * 256 * 6
+    assert lib.pa2d_gemm_fwd_workspace(512, 128, 1) == 512 * 128 * 6
+    for n, k, e in ((256, 256, 0), (256, 256, 2), (192, 256, 1), (256, 512, 1), (64, 128, 1), (2048, 256, 1)):
+        assert lib.pa2d_gemm_fwd_workspace(n, k, e) == 0, (n, k, e)
+    # dx[M, K] = dy[M, N] . w[N, K]: the GEMM's output width is K and its contraction N
+    assert lib.pa2d_gemm_bwd_data_workspace(256, 128, 1) == 256 * 128 * 4 + 256 * 128 * 6
+    assert lib.pa2d_gemm_bwd_data_workspace(256, 128, 0) == 256 * 128 * 4
+    assert lib.pa2d_gemm_bwd_data_workspace(512, 256, 1) == 512 * 256 * 4          # contraction 512: per-tile kernels
+

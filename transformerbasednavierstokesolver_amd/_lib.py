@@ -27,9 +27,10 @@ SIGNATURES = {
     "pa2d_layernorm_bwd_workspace": (_sz, [_i, _i]),
     "pa2d_layernorm_bwd": (_i, [_f, _f, _f, _f, _f, _f, _f, _f, _f, _f, _sz, _i, _i, _i, _st]),
     "pa2d_gemm_fwd_workspace": (_sz, [_i, _i, _i]),
-    "pa2d_gemm_bias_act_fwd": (_i, [_f, _ll, _f, _ll, _f, _f, _ll, _f, _ll, _f, _ll, _f, _sz, _i, _i, _i, _i, _i, _st]),
+    "pa2d_gemm_weight_image": (_i, [_f, _ll, _i, _f, _sz, _i, _i, _i, _st]),
+    "pa2d_gemm_bias_act_fwd": (_i, [_f, _ll, _f, _ll, _f, _f, _ll, _f, _ll, _f, _ll, _f, _f, _sz, _i, _i, _i, _i, _i, _st]),
     "pa2d_gemm_bwd_data_workspace": (_sz, [_i, _i, _i]),
-    "pa2d_gemm_bwd_data": (_i, [_f, _ll, _f, _ll, _f, _ll, _i, _f, _ll, _f, _sz, _i, _i, _i, _i, _st]),
+    "pa2d_gemm_bwd_data": (_i, [_f, _ll, _f, _ll, _f, _ll, _i, _f, _ll, _f, _f, _sz, _i, _i, _i, _i, _st]),
     "pa2d_gemm_bwd_weight_workspace": (_sz, [_i, _i, _i, _i]),
     "pa2d_gemm_bwd_weight": (_i, [_f, _ll, _f, _ll, _f, _f, _f, _sz, _i, _i, _i, _i, _i, _st]),
     "pa2d_conv3x3x2_workspace": (_sz, [_i, _i, _i, _i, _i]),

@@ -87,8 +87,10 @@ static int launch_kc(const KCParams& p_in, bool im2col, hipStream_t st, hipEvent
     int rc;
     if (!im2col && p.wimg && rowpanel_applies(p)) {
         // row-stationary kernel on the whole 128-row rounds, the per-tile kernels on the (< 128-row) tail
-        rc = launch_pack_weight_image(p.wsrc, p.wsn, p.wsk, p.wimg, p.N, p.K, st);
-        if (rc) return rc;
+        if (p.wsrc) {      // NULL: the caller made the image (pa2d_gemm_weight_image) while the weights stand still
+            rc = launch_pack_weight_image(p.wsrc, p.wsn, p.wsk, p.wimg, p.N, p.K, st);
+            if (rc) return rc;
+        }
         KCParams pp = p;
         pp.M = p.M - p.M % 128;
         rc = launch_kc_rowpanel(pp, p.wimg, st);
@@ -187,16 +189,30 @@ size_t pa2d_gemm_bwd_data_workspace(int N, int K, int engine) {
     return (size_t)N * K * sizeof(float) + rowpanel_image_bytes(K, N, engine);
 }
 
+// The weight plane image on its own: callers that know the weights stand still over several calls (the model calls and
+// the backward pass of one training iteration, a rollout) make it once and pass it as `wimg`.  transposed = 0: the image of
+// w[N, K] for the forward of that layer; 1: the image of w^T for its data gradient (N = the layer's input width, K = its
+// output width, w stored [K, N] with row pitch ldw).  img_bytes >= pa2d_gemm_fwd_workspace(N, K, engine) > 0.
+int pa2d_gemm_weight_image(const float* w, long long ldw, int transposed, void* img, size_t img_bytes, int N, int K,
+                           int engine, hipStream_t st) {
+    const size_t need = rowpanel_image_bytes(N, K, engine);
+    if (need == 0) return PA2D_ERR_UNSUPPORTED;
+    if (!img || img_bytes < need) return PA2D_ERR_WORKSPACE;
+    return transposed ? launch_pack_weight_image(w, 1, ldw, img, N, K, st) : launch_pack_weight_image(w, ldw, 1, img, N, K, st);
+}
+
 int pa2d_gemm_bias_act_fwd(const float* x, long long ldx, const float* w, long long ldw, const float* bias,
                            const float* res, long long ldres, float* y, long long ldy, float* pre, long long ldpre,
-                           void* ws, size_t ws_bytes, int M, int N, int K, int act, int engine, hipStream_t st) {
+                           const void* wimg, void* ws, size_t ws_bytes, int M, int N, int K, int act, int engine,
+                           hipStream_t st) {
     KCParams p = {};
     p.engine = engine;
     p.A = x; p.lda = ldx; p.B = w; p.ldb = ldw; p.C = y; p.ldc = ldy; p.bias = bias; p.res = res; p.ldres = ldres;
     p.aux = pre; p.ldaux = ldpre; p.M = M; p.N = N; p.K = K; p.act = act;
     p.epi = (act != ACT_NONE ? EPI_ACT : 0) | (pre ? EPI_STORE_PRE : 0);
     const size_t img = rowpanel_image_bytes(N, K, engine);
-    if (ws && img && ws_bytes >= img) { p.wimg = ws; p.wsrc = w; p.wsn = ldw; p.wsk = 1; }
+    if (img && wimg) p.wimg = const_cast<void*>(wimg);      // ready-made (p.wsrc stays NULL: nothing to pack)
+    else if (ws && img && ws_bytes >= img) { p.wimg = ws; p.wsrc = w; p.wsn = ldw; p.wsk = 1; }
     return launch_kc(p, false, st);
 }
 
@@ -204,8 +220,8 @@ int pa2d_gemm_bias_act_fwd(const float* x, long long ldx, const float* w, long l
 // ws: at least K*N floats (the transposed weight of the per-tile kernels); pa2d_gemm_bwd_data_workspace(N, K, engine)
 // bytes let the split engine's row-stationary kernel run: [transposed weight | weight plane image].
 int pa2d_gemm_bwd_data(const float* dy, long long lddy, const float* w, long long ldw, const float* pre,
-                       long long ldpre, int act, float* dx, long long lddx, void* ws, size_t ws_bytes, int M, int N, int K,
-                       int engine, hipStream_t st) {
+                       long long ldpre, int act, float* dx, long long lddx, const void* wimg, void* ws, size_t ws_bytes, int M,
+                       int N, int K, int engine, hipStream_t st) {
     if (ldw != K) return PA2D_ERR_ARG;
     if (N & 3) return PA2D_ERR_ARG;
     if (M <= 0) return PA2D_OK;
@@ -217,7 +233,8 @@ int pa2d_gemm_bwd_data(const float* dy, long long lddy, const float* w, long lon
     p.aux = const_cast<float*>(pre); p.ldaux = ldpre; p.act = act;
     p.epi = (pre && act != ACT_NONE) ? EPI_MUL_DACT : 0;
     const size_t img = rowpanel_image_bytes(K, N, engine);
-    if (img && ws_bytes >= (size_t)N * K * sizeof(float) + img) {
+    if (img && wimg) p.wimg = const_cast<void*>(wimg);      // ready-made image of w^T (pa2d_gemm_weight_image, transposed = 1)
+    else if (img && ws_bytes >= (size_t)N * K * sizeof(float) + img) {
         p.wimg = (char*)ws + (size_t)N * K * sizeof(float); p.wsrc = w; p.wsn = 1; p.wsk = ldw;
     }
     if (!(p.wimg && rowpanel_applies(p) && (M % 128) == 0)) {      // someone reads the fp32 transpose

@@ -166,10 +166,11 @@ def linear_fwd(x2d, w, bias=None, res=None, act=None, want_pre=False, engine=Non
     else:
         eng = _abi_engine(engine)
         nb = _L().pa2d_gemm_fwd_workspace(N, K, eng)
-        ws = _ws(nb, x2d) if nb else None
+        img = _lin_image(w, 0, N, K, eng, nb)              # inside weights_frozen(): made once per weight
+        ws = _ws(nb, x2d) if (nb and not img) else None
         _lib.check(_L().pa2d_gemm_bias_act_fwd(_p(x2d), K, _p(w), w.shape[1], _p(bias), _p(res), N, _p(y), N, _p(pre), N,
-                                               _p(ws), nb, M, N, K, ACT_IDS[act], eng, _stream()),
-                   "gemm_bias_act_fwd")
+                                               img, _p(ws), nb if ws is not None else 0, M, N, K, ACT_IDS[act], eng,
+                                               _stream()), "gemm_bias_act_fwd")
     return y, pre
 
 
@@ -186,10 +187,12 @@ def linear_bwd_data(dy, w, pre=None, act=None, engine=None):
                                                 _stream()), "gemm_bwd_data_bf16")
     else:
         eng = _abi_engine(engine)
-        nb = _L().pa2d_gemm_bwd_data_workspace(N, K, eng)
+        nimg = _L().pa2d_gemm_fwd_workspace(K, N, eng)     # the data gradient is a GEMM of output width K, contraction N
+        img = _lin_image(w, 1, K, N, eng, nimg)
+        nb = K * N * 4 if img else _L().pa2d_gemm_bwd_data_workspace(N, K, eng)
         ws = _ws(nb, dy)
-        _lib.check(_L().pa2d_gemm_bwd_data(_p(dy), N, _p(w), K, _p(pre), K, ACT_IDS[act], _p(dx), K, ws.data_ptr(), nb, M, N, K,
-                                           eng, _stream()), "gemm_bwd_data")
+        _lib.check(_L().pa2d_gemm_bwd_data(_p(dy), N, _p(w), K, _p(pre), K, ACT_IDS[act], _p(dx), K, img, ws.data_ptr(), nb,
+                                           M, N, K, eng, _stream()), "gemm_bwd_data")
     return dx
 
 
@@ -232,12 +235,15 @@ class _FrozenScope:
 
     def __init__(self):
         self.packs = {}
+        self.images = {}      # weight plane images of the row-stationary linear kernel: (w ptr, transposed, N, K, engine)
 
     def refresh(self):
         """Re-pack every entry in place (same device pointers): called before replaying a hipGraph that was captured
         inside this scope, so the graph's conv launches always see the current weights."""
         for (_, _, B, H, W, Cc, direction, eng), (wx, wf, pack) in self.packs.items():
             _make_pack(wx, wf, pack, B, H, W, Cc, direction, eng)
+        for (_, transposed, N, K, eng), (w, img) in self.images.items():
+            _make_image(w, transposed, img, N, K, eng)
 
 
 _frozen = []      # stack of active scopes
@@ -256,6 +262,26 @@ class weights_frozen:
     def __exit__(self, *exc):
         _frozen.pop()
         return False
+
+
+def _make_image(w, transposed, img, N, K, eng):
+    _lib.check(_L().pa2d_gemm_weight_image(_p(w), w.shape[1], transposed, img.data_ptr(), img.numel(), N, K, eng, _stream()),
+               "gemm_weight_image")
+
+
+def _lin_image(w, transposed, N, K, eng, nbytes):
+    """Image pointer for the active `weights_frozen()` scope (0 = let the GEMM call make it in its scratch): N, K are
+    the GEMM's output width and contraction length (forward: the layer's [N, K]; data gradient: [K, N])."""
+    if not _frozen or not nbytes:
+        return 0
+    scope = _frozen[-1]
+    key = (w.data_ptr(), transposed, N, K, eng)
+    hit = scope.images.get(key)
+    if hit is None:
+        img = torch.empty(nbytes, dtype=torch.uint8, device=w.device)
+        _make_image(w, transposed, img, N, K, eng)
+        hit = scope.images[key] = (w, img)
+    return hit[1].data_ptr()
 
 
 def _make_pack(wx, wf, pack, B, H, W, Cc, direction, eng):
