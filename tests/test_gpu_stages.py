@@ -107,6 +107,38 @@ def test_linear_row_stationary(dev, kernel_env, M, N, K):
         assert rel_l2(got[k], ref[k]) < 1e-6, k
 
 
+def test_linear_row_stationary_padded_leading_dimensions(dev):
+    """The C ABI takes leading dimensions: x, y, res and pre as column windows of wider buffers (ld = width + pad, a
+    multiple of 4 floats as the 16-byte epilogue needs; other pads fall back to the per-tile kernels) — same results,
+    and nothing outside the windows is written."""
+    from transformerbasednavierstokesolver_amd import ops, _lib
+    L = _lib.load()
+    M, N, K = 32768 + 64, 256, 256
+    rng = np.random.default_rng(5)
+    w, b = _r(rng, N, K, scale=K ** -0.5).to(dev), (0.1 * _r(rng, N)).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+    nb = L.pa2d_gemm_fwd_workspace(N, K, 1)
+    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
+    for pad in (8, 4, 6):                     # 6: the output windows are not 16-byte aligned -> per-tile kernels
+        xpad = 8
+        xb, rb = _r(rng, M, K + xpad).to(dev), _r(rng, M, N + pad).to(dev)
+        yb = torch.full((M, N + pad), 7.0, device=dev)
+        pb = torch.full((M, N + pad), 9.0, device=dev)
+        want = xb[:, :K].double() @ w.double().t() + b.double()
+        # plain + residual
+        rc = L.pa2d_gemm_bias_act_fwd(xb.data_ptr(), K + xpad, w.data_ptr(), K, b.data_ptr(), rb.data_ptr(), N + pad, yb.data_ptr(),
+                                      N + pad, 0, 0, 0, ws.data_ptr(), nb, M, N, K, 0, 1, st)
+        assert rc == 0
+        assert rel_l2(yb[:, :N], want + rb[:, :N].double()) < FWD_TOL and bool((yb[:, N:] == 7.0).all())
+        # GELU with the saved pre-activation
+        yb.fill_(7.0)
+        rc = L.pa2d_gemm_bias_act_fwd(xb.data_ptr(), K + xpad, w.data_ptr(), K, b.data_ptr(), 0, 0, yb.data_ptr(), N + pad,
+                                      pb.data_ptr(), N + pad, 0, ws.data_ptr(), nb, M, N, K, ops.ACT_IDS["gelu"], 1, st)
+        assert rc == 0
+        assert rel_l2(pb[:, :N], want) < FWD_TOL and bool((pb[:, N:] == 9.0).all()) and bool((yb[:, N:] == 7.0).all())
+        assert rel_l2(yb[:, :N], torch.nn.functional.gelu(want)) < FWD_TOL
+
+
 def _check_linear(dev, M, N, K, act, engine, FWD_TOL, BWD_TOL):
     from transformerbasednavierstokesolver_amd import ops
     from oracle import transolver_oracle as orc

@@ -362,7 +362,7 @@ int launch_conv_halo(const KCParams& p, hipStream_t st) {
     const int pitch = NT * 64 + 16;
     const int smem = HROWS * pitch + 2 * (NT == 1 ? 3 : 1) * BN * pitch;
     // the LDS attribute is set on every launch: it is per device and the call is cheap
-    if (NT == 3 && pa2d_env().conv_mfma16 && (p.N % 4) == 0) {
+    if (NT == 3 && pa2d_env().conv_mfma16 && (p.N % 4) == 0 && (p.ldc % 4) == 0) {      // 16-byte stores of accumulator quads
         const int smem16 = (HROWS + 2 * BN) * (3 * 64 + 32);
         {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_halo_kernel<3, float, 1, true>),

@@ -310,6 +310,8 @@ bool rowpanel_applies(const KCParams& p) {
     if (!pa2d_env().lin_rowpanel || p.io_bf16) return false;
     if (rowpanel_image_bytes(p.N, p.K, p.engine) == 0) return false;
     if (rowpanel_mode(p) < 0 || (p.epi == EPI_ACT && p.aux)) return false;
+    // 16-byte loads / stores of accumulator quads: every leading dimension a multiple of 4 elements
+    if ((p.lda & 3) || (p.ldc & 3) || (p.res && (p.ldres & 3)) || (p.aux && (p.ldaux & 3))) return false;
     return p.M / 128 >= 256;                                     // at least one round per CU
 }
 
