@@ -23,6 +23,7 @@ static Pa2dEnv read_env() {
     v.lin_dw_split = is("PA2D_LIN_DW_SPLIT", "of") ? 0 : 1;
     v.lin_panel = is("PA2D_LIN_PANEL", "of") ? 0 : 1;
     v.lin_rowpanel = is("PA2D_LIN_ROWPANEL", "of") ? 0 : 1;
+    v.lin_small_split = is("PA2D_LIN_SMALL_SPLIT", "of") ? 0 : 1;
     v.conv_mfma16 = num("PA2D_CONV_MFMA", 16) == 32 ? 0 : 1;
     v.split_big = num("PA2D_SPLIT_BIG", 1);
     v.slice_map = is("PA2D_SLICE_MAP", "l") ? 0 : 1;
@@ -120,6 +121,7 @@ static int launch_kc(const KCParams& p_in, bool im2col, hipStream_t st, hipEvent
             rc = launch_kc(pt, false, st);
         }
     } else if (p.io_bf16 || use_split(p.engine, p.N, im2col, p.Cin)) rc = launch_kc_split(p, im2col, st);
+    else if (kc_split_small_applies(p, im2col)) rc = launch_kc_split_small(p, st);
     else rc = launch_kc_f32(p, im2col, kc_tile(p.M, p.N, im2col, p.Cin), st);
     if (rc) return rc;
     if (ev1 && hipEventRecord(ev1, st) != hipSuccess) return PA2D_ERR_ARG;

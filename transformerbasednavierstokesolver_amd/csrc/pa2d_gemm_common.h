@@ -145,6 +145,8 @@ KCTile kc_tile(int M, int N, bool im2col, int Cin);
 int launch_kc_f32(const KCParams& p, bool im2col, const KCTile& t, hipStream_t st);
 // bf16 engines (pa2d_gemm_split.hip)
 int launch_kc_split(KCParams& p, bool im2col, hipStream_t st);
+bool kc_split_small_applies(const KCParams& p, bool im2col);
+int launch_kc_split_small(const KCParams& p, hipStream_t st);
 size_t planes_bytes(long long rows, int C, int NT);
 int launch_split_planes(const float* src, long long ld, void* dst, long long rows, int C, int NT, hipStream_t st);
 int launch_repack_split(const float* w0, const float* w1, void* dst, int bwd, int NT, int C, int Cin, hipStream_t st);

@@ -252,6 +252,27 @@ __global__ __launch_bounds__(512, (BM + BN > 256) ? 1 : 2) void gemm_kc_split_ke
 
 // Variants in use: conv (im2col) GEMMs always take pre-split activation planes (NT = 3: fp32-accurate split,
 // NT = 1: bf16 compute); plain GEMMs run only in bf16-compute mode and convert while staging.
+// Small plain GEMMs of the split engine (rollout / training at batch 1-4: a few thousand rows): 64 x 64 tiles so that
+// M = 4096, N = 256 still makes 256 workgroups, both operands split while staged.  The exact-fp32 kernel these launches
+// used to take spends 1024 matrix-pipe cycles per 32-deep K-step and wave (16 x v_mfma_f32_32x32x2_f32), this one 384.
+bool kc_split_small_applies(const KCParams& p, bool im2col) {
+    if (!pa2d_env().lin_small_split || im2col || p.io_bf16 || p.engine != 1) return false;
+    if ((p.K % 32) != 0 || p.K < 64 || p.N < 64 || p.M < 256) return false;
+    return (long long)ceil_div(p.M, 128) * ceil_div(p.N, 128) < 384;      // where kc_tile leaves the 128 x 128 tiles
+}
+int launch_kc_split_small(const KCParams& p, hipStream_t st) {
+    const int smem = 2 * (64 + 64) * 208;
+    {   // every launch: the attribute is per device, and the call is cheap
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kc_split_kernel<64, 64, false, 3, false>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (e != hipSuccess) return (int)e;
+    }
+    const dim3 grid(ceil_div(ceil_div(p.M, 64), 8) * 8 * ceil_div(p.N, 64));
+    hipLaunchKernelGGL((gemm_kc_split_kernel<64, 64, false, 3, false>), grid, dim3(512), smem, st, p);
+    PA2D_CHECK_LAUNCH();
+    return PA2D_OK;
+}
+
 int launch_kc_split(KCParams& p, bool im2col, hipStream_t st) {
     const int tiles_m = ceil_div(p.M, 128), tiles_n = ceil_div(p.N, 128);
     const bool bf = p.engine == 2;

@@ -128,6 +128,7 @@ struct Pa2dEnv {
     int lin_dw_split;     // PA2D_LIN_DW_SPLIT=off -> 0
     int lin_panel;        // PA2D_LIN_PANEL=off -> 0
     int conv_mfma16;      // PA2D_CONV_MFMA=32 -> 0 (halo conv consumers back on v_mfma_f32_32x32x16_bf16)
+    int lin_small_split;  // PA2D_LIN_SMALL_SPLIT=off -> 0 (small split-engine linears back on the exact-fp32 kernels)
     int lin_rowpanel;     // PA2D_LIN_ROWPANEL=off -> 0 (row-stationary linears back on the panel / per-tile kernels)
     int split_big;        // PA2D_SPLIT_BIG=0 -> 0
     int slice_map;        // PA2D_SLICE_MAP=legacy -> 0
