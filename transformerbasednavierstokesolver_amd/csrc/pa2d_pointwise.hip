@@ -457,6 +457,6 @@ int pa2d_act_bwd(const float* dy, const float* pre, float* out, long long n, int
     return PA2D_OK;
 }
 
-const char* pa2d_version(void) { return "pa2d 0.2 gfx950"; }
+const char* pa2d_version(void) { return "pa2d 0.3 gfx950"; }
 
 }  // extern "C"
