@@ -35,6 +35,11 @@ typedef void* pa2d_stream_t;
 #define PA2D_ERR_UNSUPPORTED 1002  /* size outside the compiled kernel grid */
 #define PA2D_ERR_WORKSPACE 1003    /* caller workspace too small */
 
+/* OR-ed into the `act` argument of the dense-layer entry points: `pre` receives (forward) / holds (data gradient)
+ * act'(pre-activation) instead of the pre-activation itself — what the backward of `act(x.w^T + b)` needs; for GELU
+ * the derivative shares every term with the activation, so saving it costs nothing and the data-gradient epilogue
+ * becomes one multiplication. */
+#define PA2D_ACT_SAVE_DERIVATIVE 0x100
 enum pa2d_act { PA2D_ACT_NONE = 0, PA2D_ACT_GELU = 1, PA2D_ACT_TANH = 2, PA2D_ACT_SIGMOID = 3,
                 PA2D_ACT_RELU = 4, PA2D_ACT_SOFTPLUS = 5, PA2D_ACT_ELU = 6, PA2D_ACT_SILU = 7 };
 

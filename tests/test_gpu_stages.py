@@ -107,6 +107,37 @@ def test_linear_row_stationary(dev, kernel_env, M, N, K):
         assert rel_l2(got[k], ref[k]) < 1e-6, k
 
 
+@pytest.mark.parametrize("engine", ENGINES + ["bf16s"])
+@pytest.mark.parametrize("M,N,K,act", [(40000, 256, 256, "gelu"), (4096, 256, 256, "gelu"), (333, 96, 200, "silu"),
+                                       (65536, 128, 128, "gelu")])
+def test_linear_saved_derivative(dev, M, N, K, act, engine):
+    """PA2D_ACT_SAVE_DERIVATIVE: the forward saves act'(pre-activation) instead of the pre-activation and the data gradient
+    multiplies by it — every kernel family (row-stationary, panel, per-tile split and exact, bf16 storage) against fp64
+    and against the plain pre-activation form."""
+    from transformerbasednavierstokesolver_amd import ops
+    from oracle import transolver_oracle as orc
+    bf = engine == "bf16s"
+    if bf and (K % 32 or N % 32):
+        pytest.skip("bf16 storage needs widths that are multiples of 32")
+    tol_f, tol_b = (2e-2, 2e-2) if bf else (FWD_TOL, BWD_TOL)
+    cast = (lambda t: t.to(dev).bfloat16()) if bf else (lambda t: t.to(dev))
+    eng = None if bf else engine
+    rng = np.random.default_rng(M + N)
+    x, w, b, dy = _r(rng, M, K), _r(rng, N, K, scale=K ** -0.5), 0.1 * _r(rng, N), _r(rng, M, N)
+    pre = (cast(x).double() @ w.to(dev).double().t() + b.to(dev).double()).requires_grad_(True)
+    orc._ACTS[act](pre).backward(torch.ones_like(pre))
+    y, d = ops.linear_fwd(cast(x), w.to(dev), b.to(dev), act=act, want_pre=True, engine=eng, save_derivative=True)
+    y0, p0 = ops.linear_fwd(cast(x), w.to(dev), b.to(dev), act=act, want_pre=True, engine=eng)
+    assert torch.equal(y, y0)
+    assert rel_l2(d, pre.grad) < (3e-2 if bf else 1e-5)
+    w2 = _r(rng, N, K, scale=N ** -0.5).to(dev)      # dx[M, K2] = (dy2 . w2) * act'(pre2), pre2 [M, K2]: reuse d as [M, N] with K2 = N
+    dy2 = cast(_r(rng, M, K))
+    got = ops.linear_bwd_data(dy2, w2.t().contiguous(), pre=d, act=act, engine=eng, pre_is_derivative=True)
+    ref = ops.linear_bwd_data(dy2, w2.t().contiguous(), pre=p0, act=act, engine=eng)
+    want = (dy2.double() @ w2.t().double()) * pre.grad
+    assert rel_l2(got, want) < tol_b and rel_l2(got, ref) < (3e-2 if bf else 1e-5)
+
+
 def test_linear_row_stationary_padded_leading_dimensions(dev):
     """The C ABI takes leading dimensions: x, y, res and pre as column windows of wider buffers (ld = width + pad, a
     multiple of 4 floats as the 16-byte epilogue needs; other pads fall back to the per-tile kernels) — same results,

@@ -209,6 +209,8 @@ int pa2d_gemm_bias_act_fwd(const float* x, long long ldx, const float* w, long l
                            hipStream_t st) {
     KCParams p = {};
     p.engine = engine;
+    p.aux_deriv = (act & PA2D_ACT_SAVE_DERIVATIVE_BIT) ? 1 : 0;
+    act &= ~PA2D_ACT_SAVE_DERIVATIVE_BIT;
     p.A = x; p.lda = ldx; p.B = w; p.ldb = ldw; p.C = y; p.ldc = ldy; p.bias = bias; p.res = res; p.ldres = ldres;
     p.aux = pre; p.ldaux = ldpre; p.M = M; p.N = N; p.K = K; p.act = act;
     p.epi = (act != ACT_NONE ? EPI_ACT : 0) | (pre ? EPI_STORE_PRE : 0);
@@ -231,6 +233,8 @@ int pa2d_gemm_bwd_data(const float* dy, long long lddy, const float* w, long lon
     float* const wt_ws = (float*)ws;
     KCParams p = {};
     p.engine = engine;
+    p.aux_deriv = (act & PA2D_ACT_SAVE_DERIVATIVE_BIT) ? 1 : 0;
+    act &= ~PA2D_ACT_SAVE_DERIVATIVE_BIT;
     p.A = dy; p.lda = lddy; p.B = wt_ws; p.ldb = N; p.C = dx; p.ldc = lddx; p.M = M; p.N = K; p.K = N;
     p.aux = const_cast<float*>(pre); p.ldaux = ldpre; p.act = act;
     p.epi = (pre && act != ACT_NONE) ? EPI_MUL_DACT : 0;
@@ -521,6 +525,8 @@ int pa2d_gemm_bias_act_fwd_bf16(const void* x, long long ldx, const float* w, lo
                                 int M, int N, int K, int act, hipStream_t st) {
     KCParams p = {};
     p.engine = 2; p.io_bf16 = 1; p.apre = 1;
+    p.aux_deriv = (act & PA2D_ACT_SAVE_DERIVATIVE_BIT) ? 1 : 0;
+    act &= ~PA2D_ACT_SAVE_DERIVATIVE_BIT;
     p.A = (const float*)x; p.lda = ldx; p.B = w; p.ldb = ldw; p.C = (float*)y; p.ldc = ldy; p.bias = bias;
     p.res = (const float*)res; p.ldres = ldres; p.aux = (float*)pre; p.ldaux = ldpre; p.M = M; p.N = N; p.K = K; p.act = act;
     p.epi = (act != ACT_NONE ? EPI_ACT : 0) | (pre ? EPI_STORE_PRE : 0);
@@ -538,6 +544,8 @@ int pa2d_gemm_bwd_data_bf16(const void* dy, long long lddy, const float* w, long
     if (rc) return rc;
     KCParams p = {};
     p.engine = 2; p.io_bf16 = 1; p.apre = 1;
+    p.aux_deriv = (act & PA2D_ACT_SAVE_DERIVATIVE_BIT) ? 1 : 0;
+    act &= ~PA2D_ACT_SAVE_DERIVATIVE_BIT;
     p.A = (const float*)dy; p.lda = lddy; p.B = wt_ws; p.ldb = N; p.C = (float*)dx; p.ldc = lddx; p.M = M; p.N = K; p.K = N;
     p.aux = (float*)const_cast<void*>(pre); p.ldaux = ldpre; p.act = act;
     p.epi = (pre && act != ACT_NONE) ? EPI_MUL_DACT : 0;

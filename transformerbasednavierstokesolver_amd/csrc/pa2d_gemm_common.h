@@ -25,6 +25,7 @@ struct KCParams {
     unsigned c_bytes, res_bytes, aux_bytes;
     int apre;   // split engine: A already holds the NT bf16 planes of every 32-channel chunk (split_planes_kernel)
     int engine; // PA2D_ENGINE_* of this call (explicit per call: the library keeps no engine state)
+    int aux_deriv; // PA2D_ACT_SAVE_DERIVATIVE: aux receives / holds act'(pre-activation) instead of the pre-activation
     void* wimg;  // scratch for the weight plane image of the row-stationary linear kernel (rowpanel_image_bytes), or NULL
     const float* wsrc; long long wsn, wsk;   // the image's source: B[n][k] = wsrc[n * wsn + k * wsk]
     int io_bf16; // bf16-storage entry points: A (row-major [M][K] or the NHWC image), C, res and aux hold bf16; lda / ldc /
@@ -59,9 +60,10 @@ __device__ __forceinline__ void kc_epilogue_tile(const KCParams& p, const f32x16
         const int row = row_base + (r & 3) + 8 * (r >> 2);
         float v = acc[r] + bv;
         if (STORE_PRE)
-            Act<TO>::bst1(raux, offc[r] != OOB_OFF ? ((unsigned)row * (unsigned)p.ldaux + (unsigned)col) * ES : OOB_OFF, v);
+            Act<TO>::bst1(raux, offc[r] != OOB_OFF ? ((unsigned)row * (unsigned)p.ldaux + (unsigned)col) * ES : OOB_OFF,
+                          p.aux_deriv ? (ACT_ID == ACT_GELU ? dgelu_f(v) : act_bwd(p.act, v)) : v);
         if (ACT) v = ACT_ID == ACT_GELU ? gelu_f(v) : act_fwd(p.act, v);
-        if (DACT) v *= ACT_ID == ACT_GELU ? dgelu_f(av[r]) : act_bwd(p.act, av[r]);
+        if (DACT) v *= p.aux_deriv ? av[r] : (ACT_ID == ACT_GELU ? dgelu_f(av[r]) : act_bwd(p.act, av[r]));
         if (HAS_RES) v += rv[r];
         Act<TO>::bst1(rc, offc[r], v);
     }

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(512, 1) void gemm_panel_kernel(const KCParams p, co
                              : ld_so<TO>(rres, vr[j_], PN_RD(i, r) * ldres_b);
 #define PN_APPLY_COL(j_)                                                                                   \
     _Pragma("unroll") for (int i = 0; i < TM; ++i) _Pragma("unroll") for (int r = 0; r < 16; ++r)          \
-        acc[i][j_][r] = MODE == 2 ? acc[i][j_][r] * dgelu_f(ov[i][r]) : acc[i][j_][r] + ov[i][r];
+        acc[i][j_][r] = MODE == 2 ? acc[i][j_][r] * (p.aux_deriv ? ov[i][r] : dgelu_f(ov[i][r])) : acc[i][j_][r] + ov[i][r];
             PN_LOAD_COL(0)
             PN_APPLY_COL(0)
             PN_LOAD_COL(1)
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(512, 1) void gemm_panel_kernel(const KCParams p, co
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        st_so<TO>(raux, vx[j], PN_RD(i, r) * ldaux_b, acc[i][j][r]);      // zero-record descriptor when aux == NULL
+                        st_so<TO>(raux, vx[j], PN_RD(i, r) * ldaux_b, p.aux_deriv ? dgelu_f(acc[i][j][r]) : acc[i][j][r]);      // zero-record descriptor when aux == NULL
                         st_so<TO>(rc, vc[j], PN_RD(i, r) * ldc_b, gelu_f(acc[i][j][r]));
                     }
         } else {

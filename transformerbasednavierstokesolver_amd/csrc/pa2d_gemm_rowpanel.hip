@@ -164,11 +164,22 @@ __global__ __launch_bounds__(256, 1) void gemm_rowpanel_kernel(const KCParams p,
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = acc[rb][nt][e];
         if (MODE == 1) {
-            st4s(raux, vx, rw * ldaux_b + cb, v);
+            if (p.aux_deriv) {               // the backward wants gelu'(pre), not pre: it shares every term with gelu(pre)
+                float d[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] = dgelu_f(v[e]);
+                st4s(raux, vx, rw * ldaux_b + cb, d);
+            } else {
+                st4s(raux, vx, rw * ldaux_b + cb, v);
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
         } else if (MODE == 2) {
-            v[0] *= dgelu_f(ov[rb][nt].x); v[1] *= dgelu_f(ov[rb][nt].y); v[2] *= dgelu_f(ov[rb][nt].z); v[3] *= dgelu_f(ov[rb][nt].w);
+            if (p.aux_deriv) {
+                v[0] *= ov[rb][nt].x; v[1] *= ov[rb][nt].y; v[2] *= ov[rb][nt].z; v[3] *= ov[rb][nt].w;
+            } else {
+                v[0] *= dgelu_f(ov[rb][nt].x); v[1] *= dgelu_f(ov[rb][nt].y); v[2] *= dgelu_f(ov[rb][nt].z); v[3] *= dgelu_f(ov[rb][nt].w);
+            }
         } else if (HAS_RES) {
             v[0] += ov[rb][nt].x; v[1] += ov[rb][nt].y; v[2] += ov[rb][nt].z; v[3] += ov[rb][nt].w;
         }

@@ -25,7 +25,11 @@ enum { ACT_NONE = 0, ACT_GELU = 1, ACT_TANH = 2, ACT_SIGMOID = 3, ACT_RELU = 4, 
 // Abramowitz-Stegun 7.1.26 rational form q(z) = (a1 t + ... + a5 t^5) exp(-z^2), t = 1/(1+p z),
 // erfc(z) = q(z) + eps, |eps| <= 1.5e-7 (fp32 level), evaluated branch-free on z = |x|/sqrt2.
 // e_out returns exp(-x^2/2) so the derivative can reuse it for the density term.
+// (contraction off: hipcc's default -ffp-contract=fast fuses `1 - hq` / `x * cdf` differently depending on what else the
+//  inlining epilogue computes from the same values, and the training forward — which also saves gelu' — must give the
+//  same bits as the inference forward)
 __device__ __forceinline__ float normal_cdf(float x, float& e_out) {
+#pragma clang fp contract(off)
     const float z = fabsf(x) * 0.70710678118654752440f;
     const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
     float poly = fmaf(1.061405429f, t, -1.453152027f);
@@ -37,8 +41,13 @@ __device__ __forceinline__ float normal_cdf(float x, float& e_out) {
     const float hq = 0.5f * poly * t * e;          // 0.5 * erfc(z)
     return x < 0.f ? hq : 1.0f - hq;
 }
-__device__ __forceinline__ float gelu_exact(float x) { float e; return x * normal_cdf(x, e); }
+__device__ __forceinline__ float gelu_exact(float x) {
+#pragma clang fp contract(off)
+    float e;
+    return x * normal_cdf(x, e);
+}
 __device__ __forceinline__ float dgelu_exact(float x) {
+#pragma clang fp contract(off)
     float e;
     const float cdf = normal_cdf(x, e);
     return fmaf(x * 0.39894228040143267794f, e, cdf);
@@ -118,6 +127,8 @@ __device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, unsigned vo
 // Kernel-selection overrides (A/B timing, and the parity tests that force one of two equivalent kernels): read from the
 // environment ONCE per process (first use) into this table; pa2d_reload_env() re-reads it (tests only).  They choose
 // between kernels that implement the same stage to the same tolerance — no numerical mode depends on them.
+#define PA2D_ACT_SAVE_DERIVATIVE_BIT 0x100      // include/pa2d.h: PA2D_ACT_SAVE_DERIVATIVE
+
 struct Pa2dEnv {
     int conv_halo;        // PA2D_CONV_HALO=off|auto|force : 0 / 1 / 2
     int mc_big_off;       // PA2D_MC_BIG=off

@@ -140,7 +140,9 @@ class PhysicsAttentionFn(Function):
 # ------------------------------------------------------------------------------ MLP (Linear-act-Linear)
 def mlp_forward(x2d, w1, b1, w2, b2, act, res2d, need_bwd=True, engine=None):
     """need_bwd=False (inference): the pre-activation is not written (one [rows, r*C] store less)."""
-    hact, hpre = ops.linear_fwd(x2d, w1, b1, act=act, want_pre=need_bwd, engine=engine)
+    # what is saved is act'(pre-activation): the only use of the pre-activation in the backward (for GELU every term of
+    # the derivative is already computed with the activation; the data-gradient epilogue becomes one multiplication)
+    hact, hpre = ops.linear_fwd(x2d, w1, b1, act=act, want_pre=need_bwd, engine=engine, save_derivative=True)
     out, _ = ops.linear_fwd(hact, w2, b2, res=res2d, engine=engine)
     return out, (x2d, hpre, hact)
 
@@ -149,7 +151,7 @@ def mlp_backward(saved, w1, w2, act, dout2d, need_dx=True, engine=None, targets=
     """`targets` = (dw1, db1, dw2, db2) buffers to add into, or None."""
     x2d, hpre, hact = saved
     t1, t2 = (None, None) if targets is None else (targets[0:2], targets[2:4])
-    dhpre = ops.linear_bwd_data(dout2d, w2, pre=hpre, act=act, engine=engine)
+    dhpre = ops.linear_bwd_data(dout2d, w2, pre=hpre, act=act, engine=engine, pre_is_derivative=True)
     dw2, db2 = ops.linear_bwd_weight(dout2d, hact, engine=engine, into=t2)
     dw1, db1 = ops.linear_bwd_weight(dhpre, x2d, engine=engine, into=t1)
     dx = ops.linear_bwd_data(dhpre, w1, engine=engine) if need_dx else None

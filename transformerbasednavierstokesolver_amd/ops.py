@@ -152,38 +152,44 @@ def layernorm_bwd(dy, x2d, mean, rstd, gamma, dres=None, into=None):
     return dx, dg, db
 
 
-def linear_fwd(x2d, w, bias=None, res=None, act=None, want_pre=False, engine=None):
-    """y = act(x . w^T + bias) (+ res); returns (y, pre) with pre = pre-activation if want_pre."""
+ACT_SAVE_DERIVATIVE = 0x100      # include/pa2d.h: PA2D_ACT_SAVE_DERIVATIVE
+
+
+def linear_fwd(x2d, w, bias=None, res=None, act=None, want_pre=False, engine=None, save_derivative=False):
+    """y = act(x . w^T + bias) (+ res); returns (y, pre) with pre = pre-activation if want_pre — or act'(pre-activation)
+    with save_derivative (what `linear_bwd_data(..., pre_is_derivative=True)` multiplies by)."""
     _chk(w, bias)
     bf = _chk_act(x2d, res)
     M, K = x2d.shape
     N = w.shape[0]
     y = torch.empty(M, N, dtype=x2d.dtype, device=x2d.device)
     pre = torch.empty_like(y) if want_pre else None
+    aflag = ACT_SAVE_DERIVATIVE if (save_derivative and want_pre and act is not None) else 0
     if bf:
         _lib.check(_L().pa2d_gemm_bias_act_fwd_bf16(_p(x2d), K, _p(w), w.shape[1], _p(bias), _p(res), N, _p(y), N,
-                                                    _p(pre), N, M, N, K, ACT_IDS[act], _stream()), "gemm_bias_act_fwd_bf16")
+                                                    _p(pre), N, M, N, K, ACT_IDS[act] | aflag, _stream()), "gemm_bias_act_fwd_bf16")
     else:
         eng = _abi_engine(engine)
         nb = _L().pa2d_gemm_fwd_workspace(N, K, eng)
         img = _lin_image(w, 0, N, K, eng, nb)              # inside weights_frozen(): made once per weight
         ws = _ws(nb, x2d) if (nb and not img) else None
         _lib.check(_L().pa2d_gemm_bias_act_fwd(_p(x2d), K, _p(w), w.shape[1], _p(bias), _p(res), N, _p(y), N, _p(pre), N,
-                                               img, _p(ws), nb if ws is not None else 0, M, N, K, ACT_IDS[act], eng,
+                                               img, _p(ws), nb if ws is not None else 0, M, N, K, ACT_IDS[act] | aflag, eng,
                                                _stream()), "gemm_bias_act_fwd")
     return y, pre
 
 
-def linear_bwd_data(dy, w, pre=None, act=None, engine=None):
-    """dx = (dy . w) * act'(pre)."""
+def linear_bwd_data(dy, w, pre=None, act=None, engine=None, pre_is_derivative=False):
+    """dx = (dy . w) * act'(pre); pre_is_derivative: `pre` already holds act'(pre-activation) (linear_fwd(save_derivative=True))."""
     _chk(w)
     bf = _chk_act(dy, pre)
     M, N = dy.shape
     K = w.shape[1]
     dx = torch.empty(M, K, dtype=dy.dtype, device=dy.device)
+    aflag = ACT_SAVE_DERIVATIVE if (pre_is_derivative and pre is not None and act is not None) else 0
     if bf:
         wt = torch.empty(K * N, dtype=torch.float32, device=dy.device)
-        _lib.check(_L().pa2d_gemm_bwd_data_bf16(_p(dy), N, _p(w), K, _p(pre), K, ACT_IDS[act], _p(dx), K, _p(wt), M, N, K,
+        _lib.check(_L().pa2d_gemm_bwd_data_bf16(_p(dy), N, _p(w), K, _p(pre), K, ACT_IDS[act] | aflag, _p(dx), K, _p(wt), M, N, K,
                                                 _stream()), "gemm_bwd_data_bf16")
     else:
         eng = _abi_engine(engine)
@@ -191,7 +197,7 @@ def linear_bwd_data(dy, w, pre=None, act=None, engine=None):
         img = _lin_image(w, 1, K, N, eng, nimg)
         nb = K * N * 4 if img else _L().pa2d_gemm_bwd_data_workspace(N, K, eng)
         ws = _ws(nb, dy)
-        _lib.check(_L().pa2d_gemm_bwd_data(_p(dy), N, _p(w), K, _p(pre), K, ACT_IDS[act], _p(dx), K, img, ws.data_ptr(), nb,
+        _lib.check(_L().pa2d_gemm_bwd_data(_p(dy), N, _p(w), K, _p(pre), K, ACT_IDS[act] | aflag, _p(dx), K, img, ws.data_ptr(), nb,
                                            M, N, K, eng, _stream()), "gemm_bwd_data")
     return dx
 
