@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mc_planes_kernel(const MCPlanesPa
     __syncthreads();
     for (int c = c_begin; c < c_end; c += KS) {
         const int buf = ((c - c_begin) / KS) & 1;
-        if (c + KS < c_end) MP_LOAD(c + KS)
+        if (c + KS < c_end) { MP_LOAD(c + KS) }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
         const unsigned char* st = smem + buf * STAGE + ks * PIMG;
@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256, 2) void gemm_mc_planes_kernel(const MCPlanesPa
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bf[j][0], acc[i][j], 0, 0, 0);
             }
         }
-        if (c + KS < c_end) MP_STORE(buf ^ 1)
+        if (c + KS < c_end) { MP_STORE(buf ^ 1) }
         __syncthreads();
     }
 #undef MP_LOAD
