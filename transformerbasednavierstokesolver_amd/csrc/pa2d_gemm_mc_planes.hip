@@ -321,11 +321,12 @@ __global__ __launch_bounds__(512, 1) void gemm_mc_planes_big_kernel(const MCPlan
             const bool okr_ = m_ < p.Mk && (c_) + ks < c_end;      /* next split's rows stay out */       \
             bool okb_ = okr_ && colok_b;                                                                  \
             int mm_ = m_;                                                                                 \
-            if (p.taps != 1) {                                                                            \
-                const int n_ = m_ % HW;                                                                   \
-                const int y_ = n_ / p.W, x_ = n_ - y_ * p.W;                                              \
-                okb_ = okb_ && (unsigned)(y_ + tap_dy) < (unsigned)p.H && (unsigned)(x_ + tap_dx) < (unsigned)p.W; \
+            if (p.taps != 1) {      /* (ly, lx) = pixel of row m_ in its image, advanced 16 rows per K-step */ \
+                okb_ = okb_ && (unsigned)(ly + tap_dy) < (unsigned)p.H && (unsigned)(lx + tap_dx) < (unsigned)p.W; \
                 mm_ = m_ + tap_shift;                                                                     \
+                lx += 16;                                                                                 \
+                while (lx >= p.W) { lx -= p.W; ++ly; }                                                    \
+                while (ly >= p.H) ly -= p.H;                                                              \
             }                                                                                             \
             const unsigned oa_ = (okr_ && colok_a) ? (unsigned)m_ * pitch_a + goff_a : OOB_OFF;           \
             const unsigned ob_ = okb_ ? (unsigned)mm_ * pitch_b + goff_b : OOB_OFF;                       \
@@ -341,6 +342,14 @@ __global__ __launch_bounds__(512, 1) void gemm_mc_planes_big_kernel(const MCPlan
             *reinterpret_cast<u32x4*>(smem + (buf_) * STAGE + s * PIMG + lds_off) = RG[s];                \
     }
     u32x4 rg0[NP];
+    // pixel coordinates of this thread's row of the NEXT K-step to be loaded: two integer divisions once, not per K-step
+    // (the loads walk the rows in order, 16 per K-step; PMC before: 2.4 vector instructions per MFMA, most of them these)
+    int ly = 0, lx = 0;
+    if (p.taps != 1) {
+        const int n0 = (c_begin * 16 + row16) % HW;
+        ly = n0 / p.W;
+        lx = n0 - ly * p.W;
+    }
 
     f32x16 acc[4][2];
 #pragma unroll
