@@ -63,7 +63,7 @@ def test_linear_row_panel(dev, M, N, K, act):
 # without the saved pre-activation, GELU' data gradient), both K, 2 / 4 / 8 column pairs, one and several rounds per
 # workgroup, a ragged tail of < 128 rows; and the same calls with the kernel switched off agree to fp32 rounding.
 @pytest.mark.parametrize("M,N,K", [(32768, 128, 128), (33285, 256, 128), (40000, 128, 256), (65536 + 128 * 5 + 77, 256, 256),
-                                   (33000, 512, 256)])
+                                   (33000, 512, 256), (32768 + 130, 1024, 128)])
 def test_linear_row_stationary(dev, kernel_env, M, N, K):
     from transformerbasednavierstokesolver_amd import ops, _lib
     from oracle import transolver_oracle as orc

@@ -194,3 +194,13 @@ def test_linear_scratch_queries():
     assert lib.pa2d_gemm_bwd_data_workspace(256, 128, 0) == 256 * 128 * 4
     assert lib.pa2d_gemm_bwd_data_workspace(512, 256, 1) == 512 * 256 * 4          # contraction 512: per-tile kernels
 
+
+def test_weight_image_entry_point_rejects_before_launching():
+    """pa2d_gemm_weight_image checks shape and buffer size on the host (no GPU needed to get the error codes)."""
+    from transformerbasednavierstokesolver_amd import _lib
+    lib = _lib.load()
+    assert lib.pa2d_gemm_weight_image(0, 256, 0, 0, 0, 192, 256, 1, 0) == 1002          # N % 128 != 0: unsupported
+    assert lib.pa2d_gemm_weight_image(0, 256, 0, 0, 0, 256, 256, 0, 0) == 1002          # exact engine: no image
+    assert lib.pa2d_gemm_weight_image(0, 256, 0, 16, 1024, 256, 256, 1, 0) == 1003      # buffer too small
+    assert lib.pa2d_gemm_weight_image(0, 256, 1, 0, 256 * 256 * 6, 256, 256, 1, 0) == 1003   # no buffer
+
